@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE metric: Mrays/s at 1080p on the treehouse scene (primary rays), plus the achieved
+algorithmic GB/s of the primary-ray DDA kernel against the MI355X HBM peak.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: a batch of N frames (N = number
+of GPUs; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips that are
+dealt round-robin to the N ranks, traced by K1 (primary-ray DDA + G-buffer), packed, and gathered to rank 0
+with ONE RCCL gather per step.  Per-GPU work per step is therefore one frame's worth of rays at every N
+("weak" scaling); value = total primary rays of all ranks / wall time.  At N = 1 there is no collective.
+
+Workload = BASELINE.json configs[1]: treehouse stand-in (synthetic:treehouse(seed=2), 256^3 -- the real
+treehouse.vox is a git-LFS pointer in the reference checkout), 1920x1080, primary rays only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured-achievable
+B_OUT = 37                     # bytes stored per pixel: the reference's 6-target G-buffer (geometry_stage.cpp:22-33)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--volume", type=int, default=256)
+    ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import voxel_raytracing_amd as vrt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    engine = vrt.Engine(local_rank)
+    W, H, NV = args.width, args.height, args.volume
+
+    # ---- synthetic scene, resident in HBM before the timed region ------------------------------------
+    vol = vrt.synthetic.treehouse(NV, seed=2)
+    pal = vrt.synthetic.default_palette(metallic_ids=range(200, 256))
+    sky, noise = vrt.synthetic.sky_gradient(512, 256), vrt.synthetic.blue_noise_standin(512)
+    scene = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
+    trav = getattr(vrt, "TRAVERSAL_" + args.traversal)
+    st = vrt.VoxelRenderSettings.primary_only((W, H), trav)
+    renderer = vrt.VoxelRenderer(engine, st, scene)
+    pos0, yaw, pitch = vrt.synthetic.default_camera_for(NV, NV, NV)
+    poses = [np.array([pos0[0] + 1.5 * f, pos0[1] + 0.5 * f, pos0[2] + 2.0 * f], np.float32) for f in range(world)]
+    sf = vrt.distributed.ShardedFrame(renderer, rank, world)
+    batch = torch.zeros((world,) + tuple(sf.packed.shape), dtype=torch.uint8, device=engine.torch_device) if world > 1 else None
+    finals = [torch.zeros((H, W, 4), dtype=torch.uint8, device=engine.torch_device) for _ in range(world)] if (world > 1 and rank == 0) else None
+    import ctypes as C
+    lib = vrt.lib()
+
+    ev_pairs = []
+
+    def step(record_events=False):
+        for f in range(world):
+            renderer.camera.position = poses[f]
+            if record_events:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            color = sf.render_local()                         # K1 on this rank's strips of frame f
+            if record_events:
+                e1.record(); ev_pairs.append((e0, e1))
+            if world > 1:
+                vrt._capi.check(lib.vrt_pack_rows(engine.ctx, color.data_ptr(), batch[f].data_ptr(), W, H, 4, C.byref(sf.shard)))
+        if world > 1:
+            bufs = vrt.distributed.gather_packed(batch, 0)    # ONE RCCL gather per step (all N frames' strips)
+            if rank == 0:
+                for src, b in enumerate(bufs):
+                    sh = vrt._capi.Shard(src, world, sf.strip_rows)
+                    for f in range(world):
+                        vrt._capi.check(lib.vrt_unpack_rows(engine.ctx, b[f].data_ptr(), finals[f].data_ptr(), W, H, 4, C.byref(sh)))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record_events=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=engine.torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    rays_per_step = world * W * H
+    value = rays_per_step * args.steps / dt / 1e6
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))     # HIP events on the launch stream
+
+    out = None
+    if rank == 0:
+        # ---- algorithmic bytes of one K1 launch: S fetches (1 B each) + W*H*B_out ----
+        st_dbg = vrt.VoxelRenderSettings.primary_only((W, H), vrt.TRAVERSAL_BITMASK)
+        renderer.camera.position = poses[0]
+        stage = vrt.GeometryStage(engine, st_dbg, scene, debug_planes=True)
+        gb = stage.record(renderer.push_constants())
+        engine.synchronize()
+        S_frame = int(gb.steps_primary.to(torch.int64).sum().item())
+        hit_frac = float((gb.hit_id != 0).float().mean().item())
+        launches_share = 1.0 / world                           # a launch covers this rank's strips of one frame
+        b_alg = (S_frame + W * H * B_OUT) * launches_share
+        achieved = b_alg / (kern_ms * 1e-3) / 1e9
+        tm = engine.last_timings()
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "k_primary", "kernel_ms": round(kern_ms, 5),
+                    "algorithmic_bytes_per_launch": int(b_alg), "dda_steps_per_frame": S_frame,
+                    "steps_per_ray": round(S_frame / (W * H), 2)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle                          # checker / CPU baseline only
+            osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
+            ncores = min(os.cpu_count() or 1, 16)
+            push = renderer.push_constants()
+            c0 = time.perf_counter()
+            exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=["hit_id", "steps_primary"], nthreads=ncores)
+            cdt = time.perf_counter() - c0
+            same = bool((exp["hit_id"] == gb.hit_id.cpu().numpy()).all()) and int(exp["steps_primary"].sum()) == S_frame
+            cpu = {"value": round(W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
+                   "sample": f"one full {W}x{H} frame of the same workload (pose 0), scalar C oracle, rows interleaved over {ncores} threads",
+                   "hit_ids_match_gpu": same}
+        out = {"metric": "Mrays/sec at 1080p treehouse.vox; achieved HBM GB/s vs MI355X peak",
+               "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"synthetic:treehouse(seed=2) {NV}^3 stand-in for treehouse.vox, {W}x{H}, primary rays only "
+                                      f"(BASELINE configs[1]); {world} frame(s)/step, 16-row strips round-robin over {world} GPU(s)"
+                                      + (", one RCCL gather/step" if world > 1 else ""),
+                          "traversal": args.traversal, "hit_fraction": round(hit_frac, 4), "bytes_out_per_px": B_OUT,
+                          "device": engine.device_info()[0]},
+               "roofline": roofline, "cpu_baseline": cpu}
+        log(f"timings of last call: {tm}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,230 @@
+/*
+ * vrt.h -- C-ABI of the MI355X-native voxel ray tracer (libvrt_hip.so).
+ *
+ * The reference (ectucker1/voxel-raytracing) has no FFI layer; the boundary this library replaces is
+ * the C++ object surface of source/voxels + source/engine.  Each entry point cites the reference
+ * interface it stands in for (paths relative to the reference root).  Plain pointers and sizes only;
+ * no exceptions cross the ABI: every call returns VRT_OK or an error code and vrt_last_error()
+ * returns the thread-local message (the reference throws std::runtime_error, app.cpp:21-25).
+ *
+ * Threading: one vrt_ctx per host thread / per GPU; calls on one context are serialised on its HIP
+ * stream (the reference is strictly single-threaded, engine.cpp:28-46).  All image pointers in
+ * vrt_frame are DEVICE pointers owned by the caller (or allocated with vrt_device_alloc).
+ * There is no CPU fallback: without a HIP device every compute call fails with VRT_ERR_NO_DEVICE.
+ */
+#ifndef VRT_H
+#define VRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_OK               0
+#define VRT_ERR_INVALID      1   /* bad argument */
+#define VRT_ERR_IO           2   /* "Failed to read voxel scene"            voxel_scene.cpp:42 */
+#define VRT_ERR_PARSE        3   /* "Could not parse voxel scene"           voxel_scene.cpp:46 */
+#define VRT_ERR_NO_INSTANCE  4   /* "Voxel scene does not contain an instance." voxel_scene.cpp:50 */
+#define VRT_ERR_NO_DEVICE    5   /* no HIP device / HIP runtime error at context creation */
+#define VRT_ERR_HIP          6   /* HIP runtime error (message has the HIP error string) */
+#define VRT_ERR_UNSUPPORTED  7
+
+#define VRT_MAX_BOUNCES 8
+
+typedef struct vrt_ctx   vrt_ctx;    /* device + stream + workspace  (stands in for Engine, engine.hpp:71-76) */
+typedef struct vrt_scene vrt_scene;  /* device-resident scene        (VoxelScene, voxel_scene.hpp:18-34)      */
+
+/* Material, source/voxels/resource/material.hpp:5-12 (32 B, std140 compatible). */
+typedef struct vrt_material {
+    float diffuse[4];
+    float metallic;
+    float pad[3];
+} vrt_material;
+
+/* ScreenQuadPush, source/voxels/resource/screen_quad_push.hpp:5-15; filled at voxel_renderer.cpp:72-83.
+ * 96 bytes, identical member offsets (camPos@0 camDir@16 camRight@32 camUp@48 volumeBounds@64 frame@76
+ * screenSize@80 cameraJitter@88). */
+typedef struct vrt_push {
+    float    cam_pos[4];
+    float    cam_dir[4];
+    float    cam_right[4];
+    float    cam_up[4];
+    uint32_t volume_bounds[3];
+    uint32_t frame;
+    int32_t  screen_size[2];
+    float    camera_jitter[2];
+} vrt_push;
+
+/* Traversal strategies.  All three produce bit-identical hit records, G-buffers and step budgets
+ * (the DDA state is advanced with the same fp32 additions, voxel_volume.frag:164-170); they differ
+ * only in how much memory work / ALU work is skipped. */
+#define VRT_TRAVERSAL_AUTO    0   /* best available (currently JUMP) */
+#define VRT_TRAVERSAL_DENSE   1   /* one R8 fetch per DDA step, literally voxel_volume.frag:157 */
+#define VRT_TRAVERSAL_BITMASK 2   /* 4^3 occupancy words (L2) + 16^3 summary staged in LDS; ALU-only stepping */
+#define VRT_TRAVERSAL_JUMP    3   /* BITMASK + exact multi-step jumps across empty pyramid cells */
+
+#define VRT_FLAG_DEBUG_PLANES 1u  /* reserved */
+
+/* VolumeParameters (parameters.hpp:5-9) + Light (voxel_scene.hpp:10-15) as GeometryStage::record fills
+ * them each frame (geometry_stage.cpp:135-145), plus the shader's compile-time constants
+ * (voxel_volume.frag:68-69,219) promoted to runtime fields. */
+typedef struct vrt_settings {
+    uint32_t ao_samples;        /* occlusionSettings.numSamples, default 4   */
+    float    ambient_intensity; /* occlusionSettings.intensity,  default 1   */
+    float    light_dir[3];      /* lightSettings.direction, default normalize(1,1,1) */
+    float    light_intensity;   /* default 1 */
+    float    light_color[4];    /* default (1,1,1,1) */
+    uint32_t max_steps;         /* MAX_RAY_STEPS   = 512 */
+    uint32_t ao_steps;          /* AO ray step cap = 64  */
+    uint32_t max_bounces;       /* MAX_REFLECTIONS = 5 (<= VRT_MAX_BOUNCES) */
+    uint32_t shadows;           /* 1 = reference behaviour; 0 = "primary rays only" (no shadow ray) */
+    uint32_t traversal;         /* VRT_TRAVERSAL_* */
+    uint32_t flags;
+} vrt_settings;
+
+/* GeometryBuffer, source/voxels/stages/geometry_stage.hpp:19-27, target formats geometry_stage.cpp:22-33.
+ * Row-major, origin top-left.  Any plane may be NULL (not written).  All DEVICE pointers.
+ * In sharded mode (vrt_shard.nranks > 1) the planes are still full-frame W*H; a rank writes only
+ * the rows it owns. */
+typedef struct vrt_frame {
+    uint8_t*  color8;        /* RGBA8_UNORM, alpha = 0                     */
+    float*    depth;         /* R32F                                        */
+    float*    motion;        /* RG32F (always 0, voxel_volume.frag:333)     */
+    uint8_t*  mask8;         /* R8_UNORM: 0.9 on hit / 0                    */
+    float*    position;      /* RGBA32F, w = 0                              */
+    int8_t*   normal8;       /* RGBA8_SNORM, w = 0                          */
+    /* debug / parity planes (no reference analogue) */
+    float*    color_f;       /* 3 floats / px before UNORM8 quantisation    */
+    uint8_t*  hit_id;        /* primary-ray material id, 0 = miss           */
+    int16_t*  hit_voxel;     /* 3 / px: grid cell of the hit                */
+    uint8_t*  hit_mask;      /* bit0..2 = final DDA mask x,y,z              */
+    uint32_t* steps_primary; /* DDA iterations that sampled a voxel (frag:157), primary ray  */
+    uint32_t* steps_total;   /* ... all rays of the pixel                   */
+    uint32_t* rays_total;    /* rays traced for the pixel                   */
+} vrt_frame;
+
+/* Screen-tile sharding (no reference analogue; BASELINE north_star).  The frame is cut into
+ * horizontal strips of strip_rows rows (multiple of 16); strip s belongs to rank s % nranks.
+ * nranks = 1 (or a NULL vrt_shard*) renders everything. */
+typedef struct vrt_shard {
+    int32_t rank;
+    int32_t nranks;
+    int32_t strip_rows;
+} vrt_shard;
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* Engine::init (engine.cpp:14): selects HIP device `device`, creates the context stream. */
+int  vrt_ctx_create(int device, vrt_ctx** out);
+void vrt_ctx_destroy(vrt_ctx* ctx);                         /* Engine::destroy */
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int  vrt_ctx_set_stream(vrt_ctx* ctx, void* hip_stream);
+int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle(), engine.cpp:351 */
+const char* vrt_last_error(void);
+/* Name of the device, compute units, and whether the library was built for its gfx arch. */
+int  vrt_device_info(vrt_ctx* ctx, char* name, size_t name_len, int* compute_units);
+
+/* Device memory helpers so that C/C++ callers need no HIP headers (Buffer, engine/resource/buffer.hpp). */
+int  vrt_device_alloc(vrt_ctx* ctx, size_t bytes, void** out);
+int  vrt_device_free(vrt_ctx* ctx, void* p);
+int  vrt_memcpy_h2d(vrt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  vrt_memcpy_d2h(vrt_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int  vrt_memset(vrt_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* ---- scene ----------------------------------------------------------------------------------- */
+/* VoxelScene::VoxelScene(engine, filename, skybox) (voxel_scene.cpp:33-133): read the file, parse the
+ * MagicaVoxel chunks (own reader, validated against ogt_vox.h:1179-1991), flatten all instances of
+ * frame 0 into one dense R8 volume with the Y/Z swap (voxel_scene.cpp:53-105), build the palette
+ * (pow 2.2 + MATL metal, :108-117), upload, and build the occupancy pyramid. */
+int  vrt_scene_load_vox_file(vrt_ctx* ctx, const char* path, vrt_scene** out);
+/* ogt_vox_read_scene(buffer,size) + the same flatten. */
+int  vrt_scene_load_vox_mem(vrt_ctx* ctx, const void* buf, size_t n, vrt_scene** out);
+/* Synthetic scenes: dense R8 volume, index x + y*W + z*W*H (Texture3D upload order, voxel_scene.cpp:99,122). */
+int  vrt_scene_from_dense(vrt_ctx* ctx, const uint8_t* voxels, uint32_t W, uint32_t H, uint32_t D,
+                          const vrt_material palette[256], vrt_scene** out);
+/* Host-only half of the loader (no device needed): parse + flatten into malloc'd host memory.
+ * *voxels must be released with vrt_host_free.  Used by tests and by the C++ host mirror. */
+int  vrt_vox_flatten_host(const void* buf, size_t n, uint32_t dims[3], uint8_t** voxels,
+                          vrt_material palette[256], uint32_t* num_instances, uint64_t* dropped);
+void vrt_host_free(void* p);
+/* Texture2D(skybox .hdr, RGBA32F) (voxel_scene.cpp:132; nearest/repeat sampler texture_2d.cpp:158-163):
+ * raw float RGBA texels, row-major.  Default when never called: 1x1 white. */
+int  vrt_scene_set_sky(vrt_ctx* ctx, vrt_scene* sc, const float* rgba, uint32_t w, uint32_t h);
+/* Texture2D(blue_noise_rgba.png, RGBA8_UNORM) (voxel_renderer.cpp:22).  Default: 1x1 mid-grey. */
+int  vrt_scene_set_blue_noise(vrt_ctx* ctx, vrt_scene* sc, const uint8_t* rgba8, uint32_t w, uint32_t h);
+/* VoxelScene::width/height/depth (voxel_scene.hpp:21). */
+int  vrt_scene_info(const vrt_scene* sc, uint32_t dims[3]);
+/* Copy the dense volume / palette back to the host (tests, oracle comparison). */
+int  vrt_scene_download(vrt_ctx* ctx, const vrt_scene* sc, uint8_t* voxels, vrt_material palette[256]);
+void vrt_scene_free(vrt_ctx* ctx, vrt_scene* sc);            /* VoxelScene::destroy */
+
+/* ---- settings -------------------------------------------------------------------------------- */
+/* Defaults of VoxelRenderSettings (voxel_render_settings.hpp:21-42) + shader constants. */
+void vrt_settings_default(vrt_settings* s);
+
+/* ---- geometry stage -------------------------------------------------------------------------- */
+/* GeometryStage::record (geometry_stage.cpp:106-153) == one full-screen run of voxel_volume.frag:
+ * primary-ray DDA kernel + (when AO / shadow / reflection rays are enabled) the secondary-ray and
+ * shading kernels.  Asynchronous on the context stream. */
+int  vrt_render_geometry(vrt_ctx* ctx, const vrt_scene* sc, const vrt_push* push,
+                         const vrt_settings* settings, const vrt_frame* frame, const vrt_shard* shard);
+
+/* ---- denoiser stage -------------------------------------------------------------------------- */
+#define VRT_DENOISE_CANONICAL  0  /* the intended 9-tap a-trous filter                               */
+#define VRT_DENOISE_AS_SHIPPED 1  /* the std140-aliased 3-tap filter the shipped UBO upload produces  */
+
+/* DenoiserSettings, voxel_render_settings.hpp:21-29. */
+typedef struct vrt_denoiser_settings {
+    int32_t iterations;     /* default 2, max 10 (MAX_DENOISER_PASSES, denoiser_stage.hpp:9) */
+    float   phi_color0;     /* 20.4 */
+    float   phi_normal0;    /* 1e-2 */
+    float   phi_pos0;       /* 1e-1 */
+    float   step_width;     /* 2.0  */
+    int32_t mode;           /* VRT_DENOISE_* */
+} vrt_denoiser_settings;
+void vrt_denoiser_settings_default(vrt_denoiser_settings* s);
+
+/* DenoiserStage::record(cmd, flightFrame, color, normal, pos) (denoiser_stage.cpp:156-258): runs
+ * `iterations` ping-pong passes of denoiser.frag:38-73 with the per-pass parameters of
+ * denoiser_stage.cpp:143-154.  target0/target1 are the two RGBA8 ping-pong images (_colorTargets);
+ * *result receives the one holding the final image (color_in itself when iterations == 0).
+ * With a shard, only the rank's own rows of the final image are valid; the guide planes must already
+ * hold `vrt_denoise_halo_rows()` valid rows either side of every owned strip. */
+int  vrt_denoise(vrt_ctx* ctx, int32_t W, int32_t H, const vrt_denoiser_settings* ds,
+                 const uint8_t* color_in, const int8_t* normal8, const float* position,
+                 uint8_t* target0, uint8_t* target1, const vrt_shard* shard, const uint8_t** result);
+/* Sum of the per-pass tap reach ceil(stepWidth_i) over all passes: rows a strip needs from its neighbours. */
+int  vrt_denoise_halo_rows(const vrt_denoiser_settings* ds);
+
+/* ---- multi-GPU strip packing (feeds the RCCL gather; no reference analogue) -------------------- */
+/* Number of rows rank owns. */
+int  vrt_shard_rows(int32_t H, const vrt_shard* shard);
+/* Pack the rows a rank owns (in increasing row order) of a full-frame plane with `bytes_per_px` into a
+ * contiguous buffer, or scatter them back (root side, after the gather).  Device pointers. */
+int  vrt_pack_rows(vrt_ctx* ctx, const void* full, void* packed, int32_t W, int32_t H,
+                   int32_t bytes_per_px, const vrt_shard* shard);
+int  vrt_unpack_rows(vrt_ctx* ctx, const void* packed, void* full, int32_t W, int32_t H,
+                     int32_t bytes_per_px, const vrt_shard* shard);
+/* Pack / unpack the halo rows exchanged with the ring neighbours before a sharded denoise:
+ * dir = -1: the first `halo` rows of every owned strip (sent to the rank owning the strip above),
+ * dir = +1: the last `halo` rows of every owned strip (sent to the rank owning the strip below).
+ * On unpack the rows land just outside the owned strips of the RECEIVING rank
+ * (dir = -1 payload came from below => written below each owned strip; +1 => above). */
+int  vrt_pack_halo(vrt_ctx* ctx, const void* full, void* packed, int32_t W, int32_t H,
+                   int32_t bytes_per_px, const vrt_shard* shard, int32_t halo, int32_t dir);
+int  vrt_unpack_halo(vrt_ctx* ctx, const void* packed, void* full, int32_t W, int32_t H,
+                     int32_t bytes_per_px, const vrt_shard* shard, int32_t halo, int32_t dir);
+size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bytes_per_px, const vrt_shard* shard, int32_t halo);
+
+/* ---- instrumentation ------------------------------------------------------------------------- */
+/* Time of the most recent vrt_render_geometry primary-ray kernel / all its kernels, and of the most
+ * recent vrt_denoise, in milliseconds (HIP events on the context stream; blocks until they complete). */
+int  vrt_last_timings(vrt_ctx* ctx, float* primary_ms, float* geometry_ms, float* denoise_ms);
+/* Enable/disable per-call event recording (default on). */
+int  vrt_ctx_set_timing(vrt_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRT_H */

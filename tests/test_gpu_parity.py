@@ -1,0 +1,198 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle on the same seeded inputs.
+
+Bar: every G-buffer plane, every debug plane and the fp32 pre-quantisation colour are BIT-EXACT
+(the numeric spec pins atan/asin/exp/normalize and forbids FMA contraction, so no tolerance is needed);
+hit voxel ids / cells / masks are integers and trivially so.  Tolerance stated per test: 0 ulp.
+"""
+import numpy as np
+import pytest
+
+from helpers import camera_push, compare_planes, metallic_palette
+
+pytestmark = pytest.mark.gpu
+
+GB = ["color8", "depth", "motion", "mask8", "position", "normal8"]
+DBG = ["color_f", "hit_id", "hit_voxel", "hit_mask", "steps_primary", "steps_total", "rays_total"]
+
+
+def _scene_pair(vrt, oracle, engine, vol, pal, sky=None, noise=None):
+    sky = sky if sky is not None else vrt.synthetic.sky_gradient(64, 32)
+    noise = noise if noise is not None else vrt.synthetic.blue_noise_standin(64)
+    gs = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
+    osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
+    return gs, osn
+
+
+def _render_both(vrt, oracle, engine, gs, osn, settings, push, shard=None):
+    stage = vrt.GeometryStage(engine, settings, gs, debug_planes=True)
+    gb = stage.record(push, shard)
+    engine.synchronize()
+    got = gb.numpy()
+    exp = oracle.render(osn, push, oracle.params_from(settings.to_c()), nthreads=8)
+    return got, exp
+
+
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP"])
+@pytest.mark.parametrize("mode", ["primary_only", "shadow_only", "default_ao_shadow_bounce"])
+def test_geometry_bit_exact_floating_cubes(vrt, oracle, engine, trav, mode):
+    vol = vrt.synthetic.floating_cubes(64, seed=1, count=120)
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    res = (96, 64)
+    st = vrt.VoxelRenderSettings.primary_only(res, getattr(vrt, "TRAVERSAL_" + trav))
+    if mode == "shadow_only":
+        st.traceSettings.shadows = True
+    elif mode == "default_ao_shadow_bounce":
+        st.traceSettings.shadows = True
+        st.traceSettings.maxReflections = 5
+        st.occlusionSettings.numSamples = 4
+    push = camera_push(vrt, (64, 64, 64), res, frame=3)
+    got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
+    names = GB + DBG if trav != "JUMP" else GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
+    bad = compare_planes(got, exp, names)
+    assert not bad, bad
+    assert (exp["hit_id"] != 0).mean() > 0.2 and (exp["hit_id"] == 0).mean() > 0.05     # both cases exercised
+    if mode == "default_ao_shadow_bounce":
+        assert (exp["rays_total"] > 6).any()                                             # some metallic bounces
+
+
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP"])
+def test_geometry_bit_exact_odd_sizes_and_views(vrt, oracle, engine, trav):
+    # non-multiple-of-4 volume, ragged frame (not a multiple of the 16x16 tile), cameras inside / above / tilted
+    rng = np.random.default_rng(12)
+    vol = (rng.random((37, 22, 51)) < 0.04).astype(np.uint8) * rng.integers(1, 256, (37, 22, 51)).astype(np.uint8)
+    pal = metallic_palette(vrt, ids=range(128, 256))
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    res = (45, 37)
+    for pos, yaw, pitch in [((25.3, 11.2, -30.0), 90.0, 0.0), ((25.3, 11.2, 18.4), 40.0, -20.0),
+                            ((-20.0, 40.0, -10.0), 30.0, -35.0), ((25.5, 60.0, 18.5), 90.0, -89.0),
+                            ((80.0, 11.0, 18.0), 180.0, 0.0)]:
+        st = vrt.VoxelRenderSettings.primary_only(res, getattr(vrt, "TRAVERSAL_" + trav))
+        st.traceSettings.shadows = True
+        st.occlusionSettings.numSamples = 2
+        st.traceSettings.maxReflections = 3
+        push = camera_push(vrt, (51, 22, 37), res, pos=pos, yaw=yaw, pitch=pitch, frame=33, jitter=(0.25, -0.4))
+        got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
+        names = GB + DBG if trav != "JUMP" else GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
+        bad = compare_planes(got, exp, names)
+        assert not bad, (pos, bad)
+
+
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP"])
+def test_exact_ties_and_axis_parallel_rays(vrt, oracle, engine, trav):
+    # camera on a lattice point looking down an axis: centre rays are axis-parallel (1/0 = inf deltas),
+    # diagonal pixels hit exact sideDist ties (multi-axis masks, diagonal normals)
+    vol = np.zeros((16, 16, 16), np.uint8)
+    vol[12, :, :] = 5
+    vol[8, 4:12, 4:12] = 9
+    vol[4, 7:9, 7:9] = 200
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    res = (32, 32)
+    st = vrt.VoxelRenderSettings.primary_only(res, getattr(vrt, "TRAVERSAL_" + trav))
+    st.traceSettings.shadows = True
+    st.traceSettings.maxReflections = 2
+    push = camera_push(vrt, (16, 16, 16), res, pos=(8.0, 8.0, -8.0))
+    got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
+    names = GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
+    bad = compare_planes(got, exp, names)
+    assert not bad, bad
+    assert np.isin(exp["hit_mask"], [3, 5, 6, 7]).any()          # tie masks occurred
+
+
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP"])
+def test_step_budget_exhaustion(vrt, oracle, engine, trav):
+    # a wall that most rays reach only after more DDA iterations than max_steps allows
+    vol = np.zeros((200, 24, 24), np.uint8); vol[190:, :, :] = 3
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    res = (48, 48)
+    for max_steps in (150, 192, 200, 260):
+        st = vrt.VoxelRenderSettings.primary_only(res, getattr(vrt, "TRAVERSAL_" + trav))
+        st.traceSettings.maxRaySteps = max_steps
+        push = camera_push(vrt, (24, 24, 200), res, pos=(12.2, 12.4, -5.0))
+        got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
+        bad = compare_planes(got, exp, GB + ["color_f", "hit_id", "hit_voxel", "hit_mask"])
+        assert not bad, (max_steps, bad)
+
+
+def test_treehouse_1080p_properties(vrt, oracle, engine):
+    """BASELINE config 2 at full size: size-independent properties + oracle parity on sampled rows."""
+    vol = vrt.synthetic.treehouse(256, seed=2)
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal, sky=vrt.synthetic.sky_gradient(512, 256),
+                          noise=vrt.synthetic.blue_noise_standin(512))
+    res = (1920, 1080)
+    pos, yaw, pitch = vrt.synthetic.default_camera_for(256, 256, 256)
+    push = camera_push(vrt, (256, 256, 256), res, pos=pos, yaw=yaw, pitch=pitch)
+    outs = {}
+    for trav in ("DENSE", "BITMASK", "JUMP"):
+        st = vrt.VoxelRenderSettings.primary_only(res, getattr(vrt, "TRAVERSAL_" + trav))
+        stage = vrt.GeometryStage(engine, st, gs, debug_planes=True)
+        gb = stage.record(push)
+        engine.synchronize()
+        outs[trav] = gb.numpy()
+    o = outs["DENSE"]
+    # traversal modes agree bit-for-bit at full size
+    for trav in ("BITMASK", "JUMP"):
+        names = GB + ["color_f", "hit_id", "hit_voxel", "hit_mask"] + (["steps_primary"] if trav == "BITMASK" else [])
+        assert not compare_planes(outs[trav], o, names), trav
+    # the hit cell really holds the reported id; misses report 0 everywhere
+    hit = o["hit_id"] != 0
+    hv = o["hit_voxel"].astype(np.int64)
+    assert (vol[hv[..., 2][hit], hv[..., 1][hit], hv[..., 0][hit]] == o["hit_id"][hit]).all()
+    assert (o["depth"][~hit] == 0).all() and (o["mask8"][~hit] == 0).all() and (o["mask8"][hit] == 230).all()
+    assert 0.3 < hit.mean() < 0.99
+    # hit position lies on the reported face of the reported cell
+    p = o["position"][..., :3][hit]
+    lo, hi = hv[hit].astype(np.float32) - 1e-3, hv[hit].astype(np.float32) + 1 + 1e-3
+    assert ((p >= lo) & (p <= hi)).all()
+    # oracle parity on a band of rows (the oracle renders 40 rows in a second or two)
+    exp = oracle.render(osn, push, oracle.params_from(st.to_c()), rows=(520, 560))
+    sub = {k: v[520:560] for k, v in o.items()}
+    esub = {k: v[520:560] for k, v in exp.items()}
+    assert not compare_planes(sub, esub, GB + DBG)
+
+
+def test_vox_file_load_matches_from_dense(vrt, oracle, engine, tmp_path):
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = open(os.path.join(gold, "vox_multi.vox"), "rb").read()
+    exp = np.load(os.path.join(gold, "vox_multi.npz"))
+    p = tmp_path / "multi.vox"
+    p.write_bytes(data)
+    sc = vrt.VoxelScene(engine, str(p))
+    assert (sc.width, sc.height, sc.depth) == exp["voxels"].shape[::-1]
+    vox, pal = sc.download()
+    assert (vox == exp["voxels"]).all() and np.allclose(pal, exp["palette"], rtol=1e-6)
+    # and it renders identically to the oracle fed with the reference parser's volume
+    osn = oracle.OracleScene(exp["voxels"], pal)
+    res = (40, 24)
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    W, H, D = sc.width, sc.height, sc.depth
+    push = camera_push(vrt, (W, H, D), res, pos=(W / 2 + 0.3, H / 2 + 0.1, -1.2 * D))
+    stage = vrt.GeometryStage(engine, st, sc, debug_planes=True)
+    gb = stage.record(push); engine.synchronize()
+    e = oracle.render(osn, push, oracle.params_from(st.to_c()))
+    assert not compare_planes(gb.numpy(), e, GB + DBG)
+    # error behaviour mirrors the reference's exceptions (voxel_scene.cpp:42,46,50)
+    with pytest.raises(RuntimeError, match="Failed to read voxel scene"):
+        vrt.VoxelScene(engine, str(tmp_path / "missing.vox"))
+    bad = tmp_path / "bad.vox"; bad.write_bytes(b"VOY " + data[4:])
+    with pytest.raises(RuntimeError, match="Could not parse voxel scene"):
+        vrt.VoxelScene(engine, str(bad))
+    with pytest.raises(RuntimeError, match="does not contain an instance"):
+        vrt.VoxelScene.from_memory(engine, open(os.path.join(gold, "vox_err_no_instance.vox"), "rb").read())
+
+
+def test_argument_validation(vrt, engine):
+    vol = vrt.synthetic.single_voxel()
+    sc = vrt.VoxelScene.from_dense(engine, vol, vrt.synthetic.default_palette())
+    st = vrt.VoxelRenderSettings.primary_only((16, 16))
+    stage = vrt.GeometryStage(engine, st, sc)
+    push = camera_push(vrt, (9, 8, 8), (16, 16))                 # wrong volume bounds
+    with pytest.raises(vrt.VrtError, match="volume_bounds"):
+        stage.record(push)
+    st.traceSettings.maxReflections = 9
+    with pytest.raises(vrt.VrtError, match="max_bounces"):
+        stage.record(camera_push(vrt, (8, 8, 8), (16, 16)))

@@ -1,0 +1,14 @@
+"""voxel_raytracing_amd -- MI355X-native backend for the per-pixel voxel traversal + denoise hot path of
+ectucker1/voxel-raytracing (shader/voxel_volume.frag + shader/denoiser.frag), behind the reference's
+.vox-load -> render-to-RGBA call surface.  HIP kernels + C-ABI: csrc/ (libvrt_hip.so, include/vrt.h);
+this package is the Python host side (ctypes) mirroring the reference's objects."""
+from . import _capi
+from ._capi import (TRAVERSAL_AUTO, TRAVERSAL_DENSE, TRAVERSAL_BITMASK, TRAVERSAL_JUMP,
+                    DENOISE_CANONICAL, DENOISE_AS_SHIPPED, VrtError, lib)
+from .host import (AmbientOcclusionSettings, CameraController, DenoiserSettings, DenoiserStage, Engine,
+                   FsrScaling, FsrSettings, GeometryBuffer, GeometryStage, LightSettings, TraceSettings,
+                   VoxelRenderSettings, VoxelRenderer, VoxelScene, make_push, make_shard, vox_flatten_host)
+from . import synthetic
+from . import distributed
+
+__all__ = [n for n in dir() if not n.startswith("_")]

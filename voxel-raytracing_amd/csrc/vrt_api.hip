@@ -1,0 +1,558 @@
+// vrt_api.hip -- the C-ABI of libvrt_hip.so (include/vrt.h): contexts, scenes, the geometry and
+// denoiser stages, strip packing.  Host code only; kernels live in vrt_device.hip.
+//
+// Call surface mirrored from the reference (paths relative to its root):
+//   VoxelScene ctor            source/voxels/resource/voxel_scene.cpp:33-133
+//   GeometryStage::record      source/voxels/stages/geometry_stage.cpp:106-153
+//   DenoiserStage::record      source/voxels/stages/denoiser_stage.cpp:143-154,156-258
+//   Engine::upload_submit      source/engine/engine.cpp:349-375 (blocking uploads)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vox_reader.h"
+#include "vrt_internal.h"
+
+using namespace vrt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+} // namespace
+
+struct vrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    bool timing = true;
+    hipEvent_t ev_geo0 = nullptr, ev_prim1 = nullptr, ev_geo1 = nullptr, ev_den0 = nullptr, ev_den1 = nullptr;
+    bool have_geo = false, have_den = false;
+    uint4* records = nullptr;
+    size_t records_px = 0;
+};
+
+struct vrt_scene {
+    DevScene d{};
+    uint8_t* vox = nullptr;
+    uint64_t *occ1 = nullptr, *occ2 = nullptr, *occ3 = nullptr;
+    vrt_material* palette = nullptr;
+    float* sky = nullptr;
+    uint8_t* noise = nullptr;
+    uint32_t occ2_bytes = 0;
+};
+
+extern "C" {
+
+const char* vrt_last_error(void) { return g_err.c_str(); }
+
+int vrt_ctx_create(int device, vrt_ctx** out)
+{
+    if (!out) return fail(VRT_ERR_INVALID, "vrt_ctx_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(VRT_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                           "); this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(VRT_ERR_INVALID, "vrt_ctx_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    vrt_ctx* c = new vrt_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(VRT_ERR_HIP, "hipStreamCreate failed"); }
+    hipEventCreate(&c->ev_geo0); hipEventCreate(&c->ev_prim1); hipEventCreate(&c->ev_geo1);
+    hipEventCreate(&c->ev_den0); hipEventCreate(&c->ev_den1);
+    *out = c;
+    return VRT_OK;
+}
+
+void vrt_ctx_destroy(vrt_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->records) hipFree(c->records);
+    hipEventDestroy(c->ev_geo0); hipEventDestroy(c->ev_prim1); hipEventDestroy(c->ev_geo1);
+    hipEventDestroy(c->ev_den0); hipEventDestroy(c->ev_den1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vrt_ctx_set_stream(vrt_ctx* c, void* hip_stream)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    c->have_geo = c->have_den = false;
+    return VRT_OK;
+}
+
+int vrt_ctx_synchronize(vrt_ctx* c)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_ctx_set_timing(vrt_ctx* c, int enabled)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    c->timing = enabled != 0;
+    return VRT_OK;
+}
+
+int vrt_device_info(vrt_ctx* c, char* name, size_t name_len, int* compute_units)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, c->device));
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    return VRT_OK;
+}
+
+int vrt_device_alloc(vrt_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return fail(VRT_ERR_INVALID, "vrt_device_alloc: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+    return VRT_OK;
+}
+
+int vrt_device_free(vrt_ctx* c, void* p)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (p) HIPCHK(hipFree(p));
+    return VRT_OK;
+}
+
+int vrt_memcpy_h2d(vrt_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_memcpy_d2h(vrt_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_memset(vrt_ctx* c, void* dst, int value, size_t bytes)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(dst, value, bytes, c->stream));
+    return VRT_OK;
+}
+
+// ---- scene ---------------------------------------------------------------------------------------
+
+void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
+{
+    if (!s) return;
+    if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    if (s->vox) hipFree(s->vox);
+    if (s->occ1) hipFree(s->occ1);
+    if (s->occ2) hipFree(s->occ2);
+    if (s->occ3) hipFree(s->occ3);
+    if (s->palette) hipFree(s->palette);
+    if (s->sky) hipFree(s->sky);
+    if (s->noise) hipFree(s->noise);
+    delete s;
+}
+
+int vrt_scene_set_sky(vrt_ctx* c, vrt_scene* s, const float* rgba, uint32_t w, uint32_t h)
+{
+    if (!c || !s || !rgba || !w || !h) return fail(VRT_ERR_INVALID, "vrt_scene_set_sky: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float* d = nullptr;
+    size_t bytes = (size_t)w * h * 16;
+    HIPCHK(hipMalloc((void**)&d, bytes));
+    HIPCHK(hipMemcpy(d, rgba, bytes, hipMemcpyHostToDevice));
+    if (s->sky) hipFree(s->sky);
+    s->sky = d; s->d.sky = d; s->d.sky_w = w; s->d.sky_h = h;
+    return VRT_OK;
+}
+
+int vrt_scene_set_blue_noise(vrt_ctx* c, vrt_scene* s, const uint8_t* rgba8, uint32_t w, uint32_t h)
+{
+    if (!c || !s || !rgba8 || !w || !h) return fail(VRT_ERR_INVALID, "vrt_scene_set_blue_noise: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint8_t* d = nullptr;
+    size_t bytes = (size_t)w * h * 4;
+    HIPCHK(hipMalloc((void**)&d, bytes));
+    HIPCHK(hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice));
+    if (s->noise) hipFree(s->noise);
+    s->noise = d; s->d.noise = d; s->d.noise_w = w; s->d.noise_h = h;
+    return VRT_OK;
+}
+
+int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t H, uint32_t D,
+                         const vrt_material palette[256], vrt_scene** out)
+{
+    if (!c || !voxels || !palette || !out) return fail(VRT_ERR_INVALID, "vrt_scene_from_dense: NULL argument");
+    if (!W || !H || !D || W > 4096 || H > 4096 || D > 4096)
+        return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_from_dense: each dimension must be in 1..4096");
+    HIPCHK(hipSetDevice(c->device));
+    vrt_scene* s = new vrt_scene();
+    DevScene& d = s->d;
+    d.W = (int)W; d.H = (int)H; d.D = (int)D;
+    d.n1x = ceil_div(d.W, 4); d.n1y = ceil_div(d.H, 4); d.n1z = ceil_div(d.D, 4);
+    d.n2x = ceil_div(d.n1x, 4); d.n2y = ceil_div(d.n1y, 4); d.n2z = ceil_div(d.n1z, 4);
+    d.n3x = ceil_div(d.n2x, 4); d.n3y = ceil_div(d.n2y, 4); d.n3z = ceil_div(d.n2z, 4);
+    size_t nvox = (size_t)W * H * D;
+    size_t n1 = (size_t)d.n1x * d.n1y * d.n1z, n2 = (size_t)d.n2x * d.n2y * d.n2z, n3 = (size_t)d.n3x * d.n3y * d.n3z;
+    size_t n2pad = (n2 + 1) & ~(size_t)1;          // 16-byte multiple for the uint4 LDS staging loop
+    int rc = VRT_OK;
+#define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
+    SCHK(hipMalloc((void**)&s->vox, nvox));
+    SCHK(hipMalloc((void**)&s->occ1, n1 * 8));
+    SCHK(hipMalloc((void**)&s->occ2, n2pad * 8));
+    SCHK(hipMalloc((void**)&s->occ3, n3 * 8));
+    SCHK(hipMalloc((void**)&s->palette, 256 * sizeof(vrt_material)));
+    SCHK(hipMemsetAsync(s->occ2, 0, n2pad * 8, c->stream));
+    SCHK(hipMemcpyAsync(s->vox, voxels, nvox, hipMemcpyHostToDevice, c->stream));
+    SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
+    SCHK(launch_build_pyramid(s->vox, d.W, d.H, d.D, s->occ1, s->occ2, s->occ3, c->stream));
+    SCHK(hipStreamSynchronize(c->stream));
+#undef SCHK
+    d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.palette = s->palette;
+    s->occ2_bytes = (uint32_t)(n2pad * 8);
+    {
+        const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        const uint8_t grey[4] = {128, 128, 128, 255};
+        rc = vrt_scene_set_sky(c, s, white, 1, 1);
+        if (rc == VRT_OK) rc = vrt_scene_set_blue_noise(c, s, grey, 1, 1);
+        if (rc != VRT_OK) goto bad;
+    }
+    *out = s;
+    return VRT_OK;
+bad:
+    vrt_scene_free(c, s);
+    return rc;
+}
+
+int vrt_vox_flatten_host(const void* buf, size_t n, uint32_t dims[3], uint8_t** voxels,
+                         vrt_material palette[256], uint32_t* num_instances, uint64_t* dropped)
+{
+    if (!buf || !dims || !voxels || !palette) return fail(VRT_ERR_INVALID, "vrt_vox_flatten_host: NULL argument");
+    FlatScene fs; std::string err;
+    int rc = vox_flatten((const uint8_t*)buf, n, fs, err);
+    if (rc != VRT_OK) return fail(rc, err);
+    dims[0] = fs.dims[0]; dims[1] = fs.dims[1]; dims[2] = fs.dims[2];
+    uint8_t* v = (uint8_t*)malloc(fs.voxels.size() ? fs.voxels.size() : 1);
+    if (!v) return fail(VRT_ERR_INVALID, "out of host memory");
+    memcpy(v, fs.voxels.data(), fs.voxels.size());
+    *voxels = v;
+    memcpy(palette, fs.palette, sizeof(fs.palette));
+    if (num_instances) *num_instances = fs.num_instances;
+    if (dropped) *dropped = fs.dropped;
+    return VRT_OK;
+}
+
+void vrt_host_free(void* p) { free(p); }
+
+int vrt_scene_load_vox_mem(vrt_ctx* c, const void* buf, size_t n, vrt_scene** out)
+{
+    if (!c || !buf || !out) return fail(VRT_ERR_INVALID, "vrt_scene_load_vox_mem: NULL argument");
+    FlatScene fs; std::string err;
+    int rc = vox_flatten((const uint8_t*)buf, n, fs, err);
+    if (rc != VRT_OK) return fail(rc, err);
+    return vrt_scene_from_dense(c, fs.voxels.data(), fs.dims[0], fs.dims[1], fs.dims[2], fs.palette, out);
+}
+
+int vrt_scene_load_vox_file(vrt_ctx* c, const char* path, vrt_scene** out)
+{
+    if (!c || !path || !out) return fail(VRT_ERR_INVALID, "vrt_scene_load_vox_file: NULL argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(VRT_ERR_IO, "Failed to read voxel scene");
+    std::vector<uint8_t> buf;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        long sz = ftell(f);
+        if (sz > 0) { buf.resize((size_t)sz); rewind(f); if (fread(buf.data(), 1, buf.size(), f) != buf.size()) buf.clear(); }
+    }
+    fclose(f);
+    if (buf.empty()) return fail(VRT_ERR_IO, "Failed to read voxel scene");
+    return vrt_scene_load_vox_mem(c, buf.data(), buf.size(), out);
+}
+
+int vrt_scene_info(const vrt_scene* s, uint32_t dims[3])
+{
+    if (!s || !dims) return fail(VRT_ERR_INVALID, "vrt_scene_info: NULL argument");
+    dims[0] = (uint32_t)s->d.W; dims[1] = (uint32_t)s->d.H; dims[2] = (uint32_t)s->d.D;
+    return VRT_OK;
+}
+
+int vrt_scene_download(vrt_ctx* c, const vrt_scene* s, uint8_t* voxels, vrt_material palette[256])
+{
+    if (!c || !s) return fail(VRT_ERR_INVALID, "vrt_scene_download: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (voxels) HIPCHK(hipMemcpy(voxels, s->vox, (size_t)s->d.W * s->d.H * s->d.D, hipMemcpyDeviceToHost));
+    if (palette) HIPCHK(hipMemcpy(palette, s->palette, 256 * sizeof(vrt_material), hipMemcpyDeviceToHost));
+    return VRT_OK;
+}
+
+// ---- settings ------------------------------------------------------------------------------------
+
+void vrt_settings_default(vrt_settings* s)
+{
+    if (!s) return;
+    memset(s, 0, sizeof *s);
+    s->ao_samples = 4;                       // voxel_render_settings.hpp:33
+    s->ambient_intensity = 1.0f;             // :34
+    const float inv = 0.57735026918962576f;  // glm::normalize(vec3(1)), :39
+    s->light_dir[0] = s->light_dir[1] = s->light_dir[2] = inv;
+    s->light_intensity = 1.0f;               // :41
+    s->light_color[0] = s->light_color[1] = s->light_color[2] = s->light_color[3] = 1.0f;  // :40
+    s->max_steps = 512;                      // voxel_volume.frag:68
+    s->ao_steps = 64;                        // voxel_volume.frag:219
+    s->max_bounces = 5;                      // voxel_volume.frag:69
+    s->shadows = 1;
+    s->traversal = VRT_TRAVERSAL_AUTO;
+    s->flags = 0;
+}
+
+void vrt_denoiser_settings_default(vrt_denoiser_settings* s)
+{
+    if (!s) return;
+    s->iterations = 2; s->phi_color0 = 20.4f; s->phi_normal0 = 1e-2f; s->phi_pos0 = 1e-1f; s->step_width = 2.0f;   // :21-29
+    s->mode = VRT_DENOISE_CANONICAL;
+}
+
+} // extern "C"
+
+// ---- shard helpers ---------------------------------------------------------------------------------
+
+namespace {
+
+int make_shard(const vrt_shard* sh, int H, ShardMap& m, int* max_local_strips)
+{
+    if (!sh || sh->nranks <= 1) {
+        m.rank = 0; m.nranks = 1; m.strip_rows = ceil_div(H, 16) * 16; m.n_local_strips = 1;
+        m.tiles_per_strip = m.strip_rows / 16;
+        if (max_local_strips) *max_local_strips = 1;
+        return VRT_OK;
+    }
+    if (sh->rank < 0 || sh->rank >= sh->nranks || sh->strip_rows <= 0 || sh->strip_rows % 16 != 0)
+        return fail(VRT_ERR_INVALID, "vrt_shard: need 0 <= rank < nranks and strip_rows a positive multiple of 16");
+    int nstrips = ceil_div(H, sh->strip_rows);
+    m.rank = sh->rank; m.nranks = sh->nranks; m.strip_rows = sh->strip_rows;
+    m.n_local_strips = nstrips > sh->rank ? ceil_div(nstrips - sh->rank, sh->nranks) : 0;
+    m.tiles_per_strip = sh->strip_rows / 16;
+    if (max_local_strips) *max_local_strips = ceil_div(nstrips, sh->nranks);
+    return VRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int vrt_shard_rows(int32_t H, const vrt_shard* sh)
+{
+    ShardMap m; int mx;
+    if (make_shard(sh, H, m, &mx) != VRT_OK) return -1;
+    if (m.nranks == 1) return H;
+    return mx * m.strip_rows;     // packed row count, identical on every rank (short ranks zero-pad)
+}
+
+// ---- geometry stage --------------------------------------------------------------------------------
+
+int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, const vrt_settings* st,
+                        const vrt_frame* frame, const vrt_shard* shard)
+{
+    if (!c || !s || !push || !st || !frame) return fail(VRT_ERR_INVALID, "vrt_render_geometry: NULL argument");
+    int W = push->screen_size[0], H = push->screen_size[1];
+    if (W <= 0 || H <= 0 || W > 32768 || H > 32768) return fail(VRT_ERR_INVALID, "vrt_render_geometry: bad screen_size");
+    if (push->volume_bounds[0] != (uint32_t)s->d.W || push->volume_bounds[1] != (uint32_t)s->d.H || push->volume_bounds[2] != (uint32_t)s->d.D)
+        return fail(VRT_ERR_INVALID, "vrt_render_geometry: push.volume_bounds must equal the scene dimensions (voxel_renderer.cpp:74)");
+    if (st->max_bounces > VRT_MAX_BOUNCES) return fail(VRT_ERR_INVALID, "vrt_render_geometry: max_bounces > VRT_MAX_BOUNCES");
+    if (st->traversal > VRT_TRAVERSAL_JUMP) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
+    HIPCHK(hipSetDevice(c->device));
+
+    GeomParams p;
+    memset(&p, 0, sizeof p);
+    p.sc = s->d; p.pc = *push; p.st = *st; p.fr = *frame;
+    int rc = make_shard(shard, H, p.sh, nullptr);
+    if (rc != VRT_OK) return rc;
+    p.tiles_x = ceil_div(W, 16);
+    p.tiles_y_local = p.sh.n_local_strips * p.sh.tiles_per_strip;
+    p.total_tiles = p.tiles_x * p.tiles_y_local;
+    p.chunk = ceil_div(p.total_tiles, 8);
+    p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : 0;
+    p.occ2_bytes = s->occ2_bytes;
+    p.occ2_in_lds = (s->occ2_bytes <= 65536) ? 1 : 0;
+    if (!p.fused_shade) {
+        size_t px = (size_t)W * (size_t)H;
+        if (c->records_px < px) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->records) hipFree(c->records);
+            c->records = nullptr; c->records_px = 0;
+            HIPCHK(hipMalloc((void**)&c->records, px * sizeof(uint4)));
+            c->records_px = px;
+        }
+        p.records = c->records;
+    }
+    if (p.total_tiles == 0) return VRT_OK;
+    if (c->timing) HIPCHK(hipEventRecord(c->ev_geo0, c->stream));
+    HIPCHK(launch_primary(p, c->stream));
+    if (c->timing) HIPCHK(hipEventRecord(c->ev_prim1, c->stream));
+    if (!p.fused_shade) HIPCHK(launch_shade(p, c->stream));
+    if (c->timing) { HIPCHK(hipEventRecord(c->ev_geo1, c->stream)); c->have_geo = true; }
+    return VRT_OK;
+}
+
+// ---- denoiser stage --------------------------------------------------------------------------------
+
+static int tap_reach(const vrt_denoiser_settings* ds, int pass)
+{
+    float sw = (float)pass * ds->step_width + 1.0f;         // denoiser_stage.cpp:151
+    int r = (int)sw; if ((float)r < sw) r++;
+    return r;
+}
+
+int vrt_denoise_halo_rows(const vrt_denoiser_settings* ds)
+{
+    if (!ds) return 0;
+    int h = 0;
+    for (int i = 0; i < ds->iterations; i++) h += tap_reach(ds, i);
+    return h;
+}
+
+int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* ds,
+                const uint8_t* color_in, const int8_t* normal8, const float* position,
+                uint8_t* target0, uint8_t* target1, const vrt_shard* shard, const uint8_t** result)
+{
+    if (!c || !ds || !color_in || !normal8 || !position || !result) return fail(VRT_ERR_INVALID, "vrt_denoise: NULL argument");
+    if (ds->iterations < 0 || ds->iterations > 10) return fail(VRT_ERR_INVALID, "vrt_denoise: iterations must be in 0..10 (MAX_DENOISER_PASSES)");
+    if (ds->iterations > 0 && !target0) return fail(VRT_ERR_INVALID, "vrt_denoise: target0 is NULL");
+    if (ds->iterations > 1 && !target1) return fail(VRT_ERR_INVALID, "vrt_denoise: target1 is NULL");
+    if (!(ds->phi_color0 > 0.0f) || !(ds->phi_normal0 > 0.0f) || !(ds->phi_pos0 > 0.0f))
+        return fail(VRT_ERR_INVALID, "vrt_denoise: phi parameters must be > 0 (SURVEY 9.4-E)");
+    if (!(ds->step_width >= 0.0f)) return fail(VRT_ERR_INVALID, "vrt_denoise: step_width must be >= 0");
+    if (W <= 0 || H <= 0) return fail(VRT_ERR_INVALID, "vrt_denoise: bad size");
+    HIPCHK(hipSetDevice(c->device));
+    DenoiseParams p;
+    memset(&p, 0, sizeof p);
+    int rc = make_shard(shard, H, p.sh, nullptr);
+    if (rc != VRT_OK) return rc;
+    p.normal = normal8; p.position = position; p.W = W; p.H = H; p.mode = ds->mode;
+    uint8_t* targets[2] = {target0, target1};
+    const uint8_t* last = color_in;
+    if (c->timing) HIPCHK(hipEventRecord(c->ev_den0, c->stream));
+    for (int i = 0; i < ds->iterations; i++) {                 // denoiser_stage.cpp:204-255
+        int ping = i % 2;
+        float inv = 1.0f / (float)i;                           // pass 0: +inf (denoiser_stage.cpp:148-150)
+        p.phi_color = inv * ds->phi_color0;
+        p.phi_normal = inv * ds->phi_normal0;
+        p.phi_pos = inv * ds->phi_pos0;
+        p.step_width = (float)i * ds->step_width + 1.0f;
+        p.color_in = last; p.color_out = targets[ping];
+        int ext = 0;
+        if (p.sh.nranks > 1) for (int j = i + 1; j < ds->iterations; j++) ext += tap_reach(ds, j);
+        p.extend = ext;
+        if (p.sh.n_local_strips > 0) HIPCHK(launch_denoise_pass(p, c->stream));
+        last = targets[ping];
+    }
+    if (c->timing) { HIPCHK(hipEventRecord(c->ev_den1, c->stream)); c->have_den = true; }
+    *result = last;
+    return VRT_OK;
+}
+
+// ---- strip packing ---------------------------------------------------------------------------------
+
+static int rows_call(vrt_ctx* c, const void* src, void* dst, int W, int H, int bpp, const vrt_shard* sh,
+                     int halo, int dir, int unpack)
+{
+    if (!c || !src || !dst) return fail(VRT_ERR_INVALID, "strip copy: NULL argument");
+    if (W <= 0 || H <= 0 || bpp <= 0 || halo < 0) return fail(VRT_ERR_INVALID, "strip copy: bad size");
+    HIPCHK(hipSetDevice(c->device));
+    RowsParams p;
+    memset(&p, 0, sizeof p);
+    int mx = 1;
+    int rc = make_shard(sh, H, p.sh, &mx);
+    if (rc != VRT_OK) return rc;
+    if (halo > p.sh.strip_rows) return fail(VRT_ERR_INVALID, "strip copy: halo larger than strip_rows");
+    p.src = (const uint8_t*)src; p.dst = (uint8_t*)dst; p.W = W; p.H = H; p.bpp = bpp;
+    p.halo = halo; p.dir = dir; p.unpack = unpack;
+    int rows = halo ? mx * halo : (p.sh.nranks == 1 ? H : mx * p.sh.strip_rows);
+    HIPCHK(launch_rows(p, rows, c->stream));
+    return VRT_OK;
+}
+
+int vrt_pack_rows(vrt_ctx* c, const void* full, void* packed, int32_t W, int32_t H, int32_t bpp, const vrt_shard* sh)
+{ return rows_call(c, full, packed, W, H, bpp, sh, 0, 0, 0); }
+
+int vrt_unpack_rows(vrt_ctx* c, const void* packed, void* full, int32_t W, int32_t H, int32_t bpp, const vrt_shard* sh)
+{ return rows_call(c, packed, full, W, H, bpp, sh, 0, 0, 1); }
+
+int vrt_pack_halo(vrt_ctx* c, const void* full, void* packed, int32_t W, int32_t H, int32_t bpp,
+                  const vrt_shard* sh, int32_t halo, int32_t dir)
+{
+    if (halo <= 0 || (dir != -1 && dir != 1)) return fail(VRT_ERR_INVALID, "vrt_pack_halo: halo > 0 and dir = +-1 required");
+    return rows_call(c, full, packed, W, H, bpp, sh, halo, dir, 0);
+}
+
+int vrt_unpack_halo(vrt_ctx* c, const void* packed, void* full, int32_t W, int32_t H, int32_t bpp,
+                    const vrt_shard* sh, int32_t halo, int32_t dir)
+{
+    if (halo <= 0 || (dir != -1 && dir != 1)) return fail(VRT_ERR_INVALID, "vrt_unpack_halo: halo > 0 and dir = +-1 required");
+    return rows_call(c, packed, full, W, H, bpp, sh, halo, dir, 1);
+}
+
+size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bpp, const vrt_shard* sh, int32_t halo)
+{
+    ShardMap m; int mx = 1;
+    if (make_shard(sh, H, m, &mx) != VRT_OK) return 0;
+    return (size_t)mx * (size_t)halo * (size_t)W * (size_t)bpp;
+}
+
+// ---- instrumentation -------------------------------------------------------------------------------
+
+int vrt_last_timings(vrt_ctx* c, float* primary_ms, float* geometry_ms, float* denoise_ms)
+{
+    if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (primary_ms) *primary_ms = -1.0f;
+    if (geometry_ms) *geometry_ms = -1.0f;
+    if (denoise_ms) *denoise_ms = -1.0f;
+    if (c->have_geo) {
+        HIPCHK(hipEventSynchronize(c->ev_geo1));
+        if (primary_ms) HIPCHK(hipEventElapsedTime(primary_ms, c->ev_geo0, c->ev_prim1));
+        if (geometry_ms) HIPCHK(hipEventElapsedTime(geometry_ms, c->ev_geo0, c->ev_geo1));
+    }
+    if (c->have_den) {
+        HIPCHK(hipEventSynchronize(c->ev_den1));
+        if (denoise_ms) HIPCHK(hipEventElapsedTime(denoise_ms, c->ev_den0, c->ev_den1));
+    }
+    return VRT_OK;
+}
+
+} // extern "C"

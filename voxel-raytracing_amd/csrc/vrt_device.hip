@@ -1,0 +1,698 @@
+// vrt_device.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4; 64-wide wavefronts).
+//
+//   k_build_occ1/2    occupancy pyramid over the dense R8 volume (scene build)
+//   k_primary<...>    K1: per-pixel ray generation + Amanatides-Woo DDA + G-buffer write
+//                     (voxel_volume.frag:309-346, :109-196 of the reference)
+//   k_shade<...>      K2: AO / shadow / mirror-bounce rays + shading (voxel_volume.frag:205-307)
+//   k_denoise         K3: one a-trous cross-bilateral pass (denoiser.frag:38-73)
+//   k_rows            strip pack / unpack for the multi-GPU gather and halo exchange
+//
+// One workgroup = 256 threads = one 16x16 screen tile; each of its 4 waves owns an 8x8 pixel block so
+// that the 64 rays of a wave stay spatially coherent.  Rays are generated in-kernel from the 96-byte
+// push-constant block (no ray buffers).  No MFMA: nothing here is a dense contraction.
+//
+// All arithmetic follows vrt_spec.h (fp32, -ffp-contract=off); the DDA state (sideDist, mapPos, mask)
+// is advanced with exactly the additions of voxel_volume.frag:164-170 in every traversal mode, so hit
+// voxel, mask, t and step budget are independent of the mode.
+#include "vrt_internal.h"
+#include "vrt_spec.h"
+
+namespace vrt {
+
+// ---------------------------------------------------------------------------------------------
+// occupancy pyramid build
+// ---------------------------------------------------------------------------------------------
+
+__global__ void k_build_occ1(const uint8_t* __restrict__ vox, int W, int H, int D,
+                             uint64_t* __restrict__ occ1, int n1x, int n1y, int n1z)
+{
+    int cx = blockIdx.x * blockDim.x + threadIdx.x;
+    int cy = blockIdx.y, cz = blockIdx.z;
+    if (cx >= n1x) return;
+    uint64_t w = 0;
+    for (int z = 0; z < 4; z++) {
+        int vz = cz * 4 + z;
+        if (vz >= D) break;
+        for (int y = 0; y < 4; y++) {
+            int vy = cy * 4 + y;
+            if (vy >= H) break;
+            size_t base = (size_t)cx * 4 + ((size_t)vy + (size_t)vz * H) * W;
+            for (int x = 0; x < 4; x++) {
+                int vx = cx * 4 + x;
+                if (vx < W && vox[base + x] != 0) w |= 1ull << (x | (y << 2) | (z << 4));
+            }
+        }
+    }
+    occ1[(size_t)cx + ((size_t)cy + (size_t)cz * n1y) * n1x] = w;
+}
+
+// level k+1 from level k: bit set <=> child word != 0
+__global__ void k_build_occ_up(const uint64_t* __restrict__ lo, int lx, int ly, int lz,
+                               uint64_t* __restrict__ hi, int hx, int hy, int hz)
+{
+    int cx = blockIdx.x * blockDim.x + threadIdx.x;
+    int cy = blockIdx.y, cz = blockIdx.z;
+    if (cx >= hx) return;
+    uint64_t w = 0;
+    for (int z = 0; z < 4; z++) {
+        int vz = cz * 4 + z;
+        if (vz >= lz) break;
+        for (int y = 0; y < 4; y++) {
+            int vy = cy * 4 + y;
+            if (vy >= ly) break;
+            for (int x = 0; x < 4; x++) {
+                int vx = cx * 4 + x;
+                if (vx < lx && lo[(size_t)vx + ((size_t)vy + (size_t)vz * ly) * lx] != 0)
+                    w |= 1ull << (x | (y << 2) | (z << 4));
+            }
+        }
+    }
+    hi[(size_t)cx + ((size_t)cy + (size_t)cz * hy) * hx] = w;
+}
+
+hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_t* occ1, uint64_t* occ2,
+                                uint64_t* occ3, hipStream_t s)
+{
+    int n1x = (W + 3) / 4, n1y = (H + 3) / 4, n1z = (D + 3) / 4;
+    int n2x = (n1x + 3) / 4, n2y = (n1y + 3) / 4, n2z = (n1z + 3) / 4;
+    int n3x = (n2x + 3) / 4, n3y = (n2y + 3) / 4, n3z = (n2z + 3) / 4;
+    hipLaunchKernelGGL(k_build_occ1, dim3((n1x + 63) / 64, n1y, n1z), dim3(64), 0, s, vox, W, H, D, occ1, n1x, n1y, n1z);
+    hipLaunchKernelGGL(k_build_occ_up, dim3((n2x + 63) / 64, n2y, n2z), dim3(64), 0, s, occ1, n1x, n1y, n1z, occ2, n2x, n2y, n2z);
+    hipLaunchKernelGGL(k_build_occ_up, dim3((n3x + 63) / 64, n3y, n3z), dim3(64), 0, s, occ2, n2x, n2y, n2z, occ3, n3x, n3y, n3z);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// traversal
+// ---------------------------------------------------------------------------------------------
+
+struct RayInt {            // RayHitInternal, voxel_volume.frag:33-41
+    f3 pos, side, delta;
+    int sx, sy, sz;        // rayStep
+    int mx, my, mz;        // mapPos at loop exit
+    uint32_t material;
+    uint32_t mask;         // bit0..2
+    uint32_t fetches;      // iterations that sampled a voxel (voxel_volume.frag:157)
+};
+
+struct RayHit {            // RayHit, voxel_volume.frag:43-49
+    uint32_t material;
+    f3 pos, normal, dir;
+};
+
+// The occ1 word of 4^3 cell (cx,cy,cz): the 16^3 summary (LDS or L2) is consulted first so that empty
+// space costs no global-memory transaction at all.
+template <bool OCC2_LDS>
+__device__ __forceinline__ uint64_t fetch_cell(const DevScene& s, const uint64_t* locc2, int cx, int cy, int cz)
+{
+    int i2 = (cx >> 2) + ((cy >> 2) + (cz >> 2) * s.n2y) * s.n2x;
+    uint64_t w2 = OCC2_LDS ? locc2[i2] : s.occ2[i2];
+    uint32_t b = (uint32_t)(cx & 3) | ((uint32_t)(cy & 3) << 2) | ((uint32_t)(cz & 3) << 4);
+    if (!((w2 >> b) & 1ull)) return 0ull;
+    return s.occ1[cx + (cy + cz * s.n1y) * s.n1x];
+}
+
+// traceRayInt, voxel_volume.frag:127-174 (+ boxIntersection :109-125).
+template <int TRAV, bool OCC2_LDS>
+__device__ __forceinline__ void trace_int(const DevScene& s, const uint64_t* locc2, f3 start, f3 dir,
+                                          uint32_t maxSteps, RayInt& r)
+{
+    // boxIntersection
+    float ivx = 1.0f / dir.x, ivy = 1.0f / dir.y, ivz = 1.0f / dir.z;
+    float t1x = (-start.x) * ivx, t2x = ((float)s.W - start.x) * ivx;
+    float t1y = (-start.y) * ivy, t2y = ((float)s.H - start.y) * ivy;
+    float t1z = (-start.z) * ivz, t2z = ((float)s.D - start.z) * ivz;
+    float tnx = fminf(t1x, t2x), tny = fminf(t1y, t2y), tnz = fminf(t1z, t2z);
+    float txx = fmaxf(t1x, t2x), txy = fmaxf(t1y, t2y), txz = fmaxf(t1z, t2z);
+    float tmin = fmaxf(tnx, fmaxf(tny, tnz));
+    float tmax = fminf(txx, fminf(txy, txz));
+    f3 p = start;
+    uint32_t mask = 0;
+    if (tmin >= 0.0f && tmax >= tmin) {
+        float t = tmin + 0.1f;
+        p = mk3(start.x + t * dir.x, start.y + t * dir.y, start.z + t * dir.z);
+        mask = (uint32_t)(tnx == tmin) | ((uint32_t)(tny == tmin) << 1) | ((uint32_t)(tnz == tmin) << 2);
+    }
+    int mx = (int)floorf(p.x), my = (int)floorf(p.y), mz = (int)floorf(p.z);
+    float dx = fabsf(ivx), dy = fabsf(ivy), dz = fabsf(ivz);
+    float gx = fsign(dir.x), gy = fsign(dir.y), gz = fsign(dir.z);
+    int sx = (int)gx, sy = (int)gy, sz = (int)gz;
+    float sdx = ((gx * ((float)mx - p.x) + gx * 0.5f) + 0.5f) * dx;
+    float sdy = ((gy * ((float)my - p.y) + gy * 0.5f) + 0.5f) * dy;
+    float sdz = ((gz * ((float)mz - p.z) + gz * 0.5f) + 0.5f) * dz;
+
+    uint32_t material = 0, fetches = 0;
+    uint32_t ckey = 0xFFFFFFFFu;
+    uint64_t word = 0;
+    uint32_t i = 0;
+    for (; i < maxSteps; i++) {
+        if ((uint32_t)mx >= (uint32_t)s.W || (uint32_t)my >= (uint32_t)s.H || (uint32_t)mz >= (uint32_t)s.D) break;
+        if (TRAV == VRT_TRAVERSAL_DENSE) {
+            material = s.vox[(size_t)mx + ((size_t)my + (size_t)mz * s.H) * s.W];
+            if (material != 0) { fetches = i + 1; break; }
+        } else {
+            uint32_t key = (uint32_t)(mx >> 2) | ((uint32_t)(my >> 2) << 10) | ((uint32_t)(mz >> 2) << 20);
+            if (key != ckey) { ckey = key; word = fetch_cell<OCC2_LDS>(s, locc2, mx >> 2, my >> 2, mz >> 2); }
+            uint32_t bit = (uint32_t)(mx & 3) | ((uint32_t)(my & 3) << 2) | ((uint32_t)(mz & 3) << 4);
+            if ((word >> bit) & 1ull) {
+                material = s.vox[(size_t)mx + ((size_t)my + (size_t)mz * s.H) * s.W];
+                fetches = i + 1;
+                break;
+            }
+        }
+        bool m0 = sdx <= fminf(sdy, sdz);
+        bool m1 = sdy <= fminf(sdz, sdx);
+        bool m2 = sdz <= fminf(sdx, sdy);
+        mask = (uint32_t)m0 | ((uint32_t)m1 << 1) | ((uint32_t)m2 << 2);
+        if (m0) { sdx = sdx + dx; mx += sx; }
+        if (m1) { sdy = sdy + dy; my += sy; }
+        if (m2) { sdz = sdz + dz; mz += sz; }
+    }
+    if (material == 0) fetches = i;
+    r.pos = p; r.side = mk3(sdx, sdy, sdz); r.delta = mk3(dx, dy, dz);
+    r.sx = sx; r.sy = sy; r.sz = sz; r.mx = mx; r.my = my; r.mz = mz;
+    r.material = material; r.mask = mask; r.fetches = fetches;
+}
+
+__device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
+{
+    f3 n = mk3((mask & 1u) ? (float)(-sx) : 0.0f, (mask & 2u) ? (float)(-sy) : 0.0f, (mask & 4u) ? (float)(-sz) : 0.0f);
+    return normalize3(n);
+}
+
+// traceRay, voxel_volume.frag:176-196
+template <int TRAV, bool OCC2_LDS>
+__device__ __forceinline__ void trace_ray(const DevScene& s, const uint64_t* locc2, f3 start, f3 dir,
+                                          uint32_t maxSteps, RayHit& h, RayInt& r)
+{
+    trace_int<TRAV, OCC2_LDS>(s, locc2, start, dir, maxSteps, r);
+    h.material = r.material;
+    h.dir = dir;
+    if (r.material != 0) {
+        h.normal = hit_normal(r.mask, r.sx, r.sy, r.sz);
+        f3 m = mk3((r.mask & 1u) ? (r.side.x - r.delta.x) : 0.0f,
+                   (r.mask & 2u) ? (r.side.y - r.delta.y) : 0.0f,
+                   (r.mask & 4u) ? (r.side.z - r.delta.z) : 0.0f);
+        float d = len3(m);
+        h.pos = mk3(r.pos.x + d * dir.x, r.pos.y + d * dir.y, r.pos.z + d * dir.z);
+    } else {
+        h.pos = mk3(0.0f, 0.0f, 0.0f);
+        h.normal = mk3(0.0f, 0.0f, 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shading helpers
+// ---------------------------------------------------------------------------------------------
+
+struct PixCtx { int px, py; uint32_t fetches, rays; };
+
+// skyColor, voxel_volume.frag:98-105
+__device__ __forceinline__ f3 sky_color(const DevScene& s, f3 d)
+{
+    float u = atan2_spec(d.z, d.x) * 0.1591f + 0.5f;
+    float v = asin_spec(-d.y) * 0.3183f + 0.5f;
+    uint32_t x = wrap_texel(u, s.sky_w), y = wrap_texel(v, s.sky_h);
+    const float4 t = reinterpret_cast<const float4*>(s.sky)[(size_t)y * s.sky_w + x];
+    return mk3(t.x, t.y, t.z);
+}
+
+// fragmentNoiseSeq + randomDir, voxel_volume.frag:80-95
+__device__ __forceinline__ f3 random_dir(const DevScene& s, const vrt_push& pc, const PixCtx& c, uint32_t num)
+{
+    uint32_t offset = num * 32u + pc.frame % 32u;
+    const float g = 1.22074408460575947536f;
+    const float a0 = 1.0f / g, a1 = 1.0f / (g * g), a2 = 1.0f / ((g * g) * g);
+    float pxf = ((float)c.px + 0.5f) / 512.0f + 0.5f;
+    float pyf = ((float)c.py + 0.5f) / 512.0f + 0.5f;
+    uint32_t tx = wrap_texel(pxf, s.noise_w), ty = wrap_texel(pyf, s.noise_h);
+    const uchar4 t = reinterpret_cast<const uchar4*>(s.noise)[(size_t)ty * s.noise_w + tx];
+    float fo = (float)offset;
+    float n0 = (float)t.x / 255.0f + fo * a0;
+    float n1 = (float)t.y / 255.0f + fo * a1;
+    float n2 = (float)t.z / 255.0f + fo * a2;
+    n0 = n0 - floorf(n0); n1 = n1 - floorf(n1); n2 = n2 - floorf(n2);
+    return normalize3(mk3(n0 * 2.0f - 1.0f, n1 * 2.0f - 1.0f, n2 * 2.0f - 1.0f));
+}
+
+// main() ray generation, voxel_volume.frag:312-322 (+ screen_quad.vert:18-31)
+__device__ __forceinline__ f3 primary_dir(const vrt_push& pc, int px, int py)
+{
+    float W = (float)pc.screen_size[0], H = (float)pc.screen_size[1];
+    float sx = (((float)px + 0.5f) / W) * 2.0f - 1.0f;
+    float sy = (((float)py + 0.5f) / H) * 2.0f - 1.0f;
+    f3 cd = normalize3(mk3(pc.cam_dir[0], pc.cam_dir[1], pc.cam_dir[2]));
+    float jx = (pc.camera_jitter[0] / W) * -2.0f;
+    float jy = (pc.camera_jitter[1] / H) * 2.0f;
+    float vx = ((cd.x + sx * pc.cam_right[0]) + sy * ((pc.cam_up[0] * H) / W)) + jx;
+    float vy = ((cd.y + sx * pc.cam_right[1]) + sy * ((pc.cam_up[1] * H) / W)) + jy;
+    float vz = ((cd.z + sx * pc.cam_right[2]) + sy * ((pc.cam_up[2] * H) / W)) + 0.0f;
+    return normalize3(mk3(vx, vy, vz));
+}
+
+// calcAmbient + isShadowed + color + colorHit, voxel_volume.frag:205-264
+template <int TRAV, bool OCC2_LDS>
+__device__ f3 color_hit(const GeomParams& P, const uint64_t* locc2, PixCtx& c, const RayHit& hit,
+                        f3 reflection, uint32_t depth)
+{
+    const DevScene& s = P.sc;
+    const vrt_settings& st = P.st;
+    if (hit.material == 0) return sky_color(s, hit.dir);
+
+    float ambient = 0.0f;
+    if (st.ao_samples == 0) {
+        ambient = 1.0f;
+    } else {
+        float sample_frac = 1.0f / (float)st.ao_samples;
+        for (uint32_t i = 0; i < st.ao_samples; i++) {
+            f3 rd = random_dir(s, P.pc, c, i + depth * st.ao_samples);
+            f3 dir = mk3(hit.normal.x + rd.x, hit.normal.y + rd.y, hit.normal.z + rd.z);
+            f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
+            RayInt r;
+            trace_int<TRAV, OCC2_LDS>(s, locc2, o, dir, st.ao_steps, r);
+            c.fetches += r.fetches; c.rays++;
+            if (r.material != 0) ambient += sample_frac;
+        }
+    }
+    f3 sky = sky_color(s, hit.normal);
+    float k = ambient * st.ambient_intensity;
+    f3 amb = mk3(k * sky.x, k * sky.y, k * sky.z);
+
+    bool shadowed = false;
+    f3 L = mk3(st.light_dir[0], st.light_dir[1], st.light_dir[2]);
+    if (st.shadows) {
+        f3 o = mk3(hit.pos.x + hit.normal.x * 0.01f, hit.pos.y + hit.normal.y * 0.01f, hit.pos.z + hit.normal.z * 0.01f);
+        RayInt r;
+        trace_int<TRAV, OCC2_LDS>(s, locc2, o, L, st.max_steps, r);
+        c.fetches += r.fetches; c.rays++;
+        shadowed = r.material != 0;
+    }
+    f3 diffuse = mk3(0.0f, 0.0f, 0.0f);
+    if (!shadowed) {
+        float diff = fmaxf(dot3(hit.normal, L), 0.0f);
+        diffuse = mk3((diff * st.light_color[0]) * st.light_intensity,
+                      (diff * st.light_color[1]) * st.light_intensity,
+                      (diff * st.light_color[2]) * st.light_intensity);
+    }
+    const vrt_material mat = s.palette[hit.material];
+    float inv = (float)(depth + 1);
+    f3 out;
+    out.x = ((((diffuse.x + reflection.x * mat.metallic) + amb.x) * mat.diffuse[0]) * 1.0f) / inv;
+    out.y = ((((diffuse.y + reflection.y * mat.metallic) + amb.y) * mat.diffuse[1]) * 1.0f) / inv;
+    out.z = ((((diffuse.z + reflection.z * mat.metallic) + amb.z) * mat.diffuse[2]) * 1.0f) / inv;
+    return out;
+}
+
+// colorMainRay, voxel_volume.frag:267-307
+template <int TRAV, bool OCC2_LDS>
+__device__ f3 color_main_ray(const GeomParams& P, const uint64_t* locc2, PixCtx& c, const RayHit& hit)
+{
+    const DevScene& s = P.sc;
+    const vrt_settings& st = P.st;
+    f3 reflection = mk3(0.0f, 0.0f, 0.0f);
+    if (s.palette[hit.material].metallic > 0.0f && st.max_bounces > 0) {
+        RayHit bounces[VRT_MAX_BOUNCES];
+        RayHit last = hit;
+        int last_idx = -1;
+        int nb = st.max_bounces > VRT_MAX_BOUNCES ? VRT_MAX_BOUNCES : (int)st.max_bounces;
+        for (int i = 0; i < nb; i++) {
+            float k = 2.0f * dot3(last.normal, last.dir);
+            f3 rdir = mk3(last.dir.x - k * last.normal.x, last.dir.y - k * last.normal.y, last.dir.z - k * last.normal.z);
+            f3 o = mk3(last.pos.x + last.normal.x * 0.01f, last.pos.y + last.normal.y * 0.01f, last.pos.z + last.normal.z * 0.01f);
+            RayHit rh; RayInt ri;
+            trace_ray<TRAV, OCC2_LDS>(s, locc2, o, rdir, st.max_steps, rh, ri);
+            c.fetches += ri.fetches; c.rays++;
+            bounces[i] = rh;
+            last = rh;
+            if (last.material == 0 || s.palette[last.material].metallic <= 0.0f) { last_idx = i; break; }
+        }
+        for (int i = last_idx; i >= 0; i--) {
+            f3 col = color_hit<TRAV, OCC2_LDS>(P, locc2, c, bounces[i], reflection, (uint32_t)i);
+            reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
+        }
+    }
+    return color_hit<TRAV, OCC2_LDS>(P, locc2, c, hit, reflection, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile mapping
+// ---------------------------------------------------------------------------------------------
+
+// Workgroup -> screen tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
+// XCD and its private 4 MiB L2), so XCD slot (b % 8) gets one contiguous run of `chunk` tiles in
+// row-major tile order: neighbouring tiles traverse neighbouring volume cells and share L2 lines.
+__device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y0)
+{
+    int b = blockIdx.x;
+    int t = (b & 7) * P.chunk + (b >> 3);
+    if ((b >> 3) >= P.chunk || t >= P.total_tiles) return false;
+    int tx = t % P.tiles_x, ty = t / P.tiles_x;
+    int strip_local = ty / P.sh.tiles_per_strip, within = ty % P.sh.tiles_per_strip;
+    x0 = tx * 16;
+    y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + within * 16;
+    return y0 < P.pc.screen_size[1];
+}
+
+__device__ __forceinline__ void stage_occ2(const GeomParams& P, uint64_t* locc2)
+{
+    // 16 B per lane per iteration, coalesced; the summary is <= 64 KiB by construction.
+    const uint4* src = reinterpret_cast<const uint4*>(P.sc.occ2);
+    uint4* dst = reinterpret_cast<uint4*>(locc2);
+    uint32_t n16 = P.occ2_bytes / 16;
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: primary rays
+// ---------------------------------------------------------------------------------------------
+
+template <int TRAV, bool OCC2_LDS, bool FUSED>
+__global__ __launch_bounds__(256) void k_primary(const GeomParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t locc2[];
+    int x0, y0;
+    bool live = tile_origin(P, x0, y0);          // uniform per workgroup
+    if (!live) return;
+    if (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) stage_occ2(P, locc2);
+
+    // wave w -> 8x8 block (w&1, w>>1); lane -> (l&7, l>>3)
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int px = x0 + (wave & 1) * 8 + (lane & 7);
+    int py = y0 + (wave >> 1) * 8 + (lane >> 3);
+    int W = P.pc.screen_size[0], H = P.pc.screen_size[1];
+    if (px >= W || py >= H) return;
+    size_t i = (size_t)py * (size_t)W + (size_t)px;
+
+    const DevScene& s = P.sc;
+    f3 start = mk3(P.pc.cam_pos[0], P.pc.cam_pos[1], P.pc.cam_pos[2]);
+    f3 dir = primary_dir(P.pc, px, py);
+    RayHit h; RayInt r;
+    trace_ray<TRAV, OCC2_LDS>(s, locc2, start, dir, P.st.max_steps, h, r);
+    bool hit = h.material != 0;
+
+    const vrt_frame& f = P.fr;
+    float depth = 0.0f;
+    if (hit) depth = len3(mk3(h.pos.x - start.x, h.pos.y - start.y, h.pos.z - start.z));
+    if (f.depth) f.depth[i] = depth;
+    if (f.motion) reinterpret_cast<float2*>(f.motion)[i] = make_float2(0.0f, 0.0f);
+    if (f.mask8) f.mask8[i] = unorm8(hit ? 0.9f : 0.0f);
+    if (f.position) reinterpret_cast<float4*>(f.position)[i] = make_float4(h.pos.x, h.pos.y, h.pos.z, 0.0f);
+    if (f.normal8) {
+        char4 n; n.x = snorm8(h.normal.x); n.y = snorm8(h.normal.y); n.z = snorm8(h.normal.z); n.w = 0;
+        reinterpret_cast<char4*>(f.normal8)[i] = n;
+    }
+    if (f.hit_id) f.hit_id[i] = (uint8_t)h.material;
+    if (f.hit_voxel) {
+        f.hit_voxel[i * 3 + 0] = hit ? (int16_t)r.mx : (int16_t)0;
+        f.hit_voxel[i * 3 + 1] = hit ? (int16_t)r.my : (int16_t)0;
+        f.hit_voxel[i * 3 + 2] = hit ? (int16_t)r.mz : (int16_t)0;
+    }
+    if (f.hit_mask) f.hit_mask[i] = hit ? (uint8_t)r.mask : (uint8_t)0;
+    if (f.steps_primary) f.steps_primary[i] = r.fetches;
+    if (f.steps_total) f.steps_total[i] = r.fetches;
+    if (f.rays_total) f.rays_total[i] = 1;
+
+    if (FUSED) {
+        // no secondary rays enabled: shade here (ambient = 1, not shadowed, reflection = 0)
+        f3 col;
+        if (hit) {
+            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
+            col = color_hit<TRAV, OCC2_LDS>(P, locc2, c, h, mk3(0.0f, 0.0f, 0.0f), 0);
+        } else {
+            col = sky_color(s, dir);
+        }
+        if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
+        if (f.color8) {
+            uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
+            reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+        }
+    } else {
+        // hit record for K2: position bits + material | mask << 8 | (step+1) codes
+        uint32_t packed = h.material | (r.mask << 8) | ((uint32_t)(r.sx + 1) << 11) | ((uint32_t)(r.sy + 1) << 13) |
+                          ((uint32_t)(r.sz + 1) << 15);
+        P.records[i] = make_uint4(__float_as_uint(h.pos.x), __float_as_uint(h.pos.y), __float_as_uint(h.pos.z), packed);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: secondary rays + shading
+// ---------------------------------------------------------------------------------------------
+
+template <int TRAV, bool OCC2_LDS>
+__global__ __launch_bounds__(256) void k_shade(const GeomParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t locc2[];
+    int x0, y0;
+    bool live = tile_origin(P, x0, y0);
+    if (!live) return;
+    if (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) stage_occ2(P, locc2);
+
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int px = x0 + (wave & 1) * 8 + (lane & 7);
+    int py = y0 + (wave >> 1) * 8 + (lane >> 3);
+    int W = P.pc.screen_size[0], H = P.pc.screen_size[1];
+    if (px >= W || py >= H) return;
+    size_t i = (size_t)py * (size_t)W + (size_t)px;
+
+    const DevScene& s = P.sc;
+    uint4 rec = P.records[i];
+    RayHit h;
+    h.material = rec.w & 0xFFu;
+    h.dir = primary_dir(P.pc, px, py);
+    h.pos = mk3(__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z));
+    uint32_t mask = (rec.w >> 8) & 7u;
+    int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;
+    PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
+    f3 col;
+    if (h.material != 0) {
+        h.normal = hit_normal(mask, sx, sy, sz);
+        col = color_main_ray<TRAV, OCC2_LDS>(P, locc2, c, h);
+    } else {
+        h.normal = mk3(0.0f, 0.0f, 0.0f);
+        col = sky_color(s, h.dir);
+    }
+    const vrt_frame& f = P.fr;
+    if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
+    if (f.color8) {
+        uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
+        reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+    }
+    if (f.steps_total) f.steps_total[i] += c.fetches;
+    if (f.rays_total) f.rays_total[i] += c.rays;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch plumbing for K1 / K2
+// ---------------------------------------------------------------------------------------------
+
+template <int TRAV, bool OCC2_LDS>
+static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
+{
+    dim3 grid((unsigned)(p.chunk * 8)), block(256);
+    size_t lds = (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes : 0;
+    if (p.fused_shade) hipLaunchKernelGGL((k_primary<TRAV, OCC2_LDS, true>), grid, block, lds, s, p);
+    else               hipLaunchKernelGGL((k_primary<TRAV, OCC2_LDS, false>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+template <int TRAV, bool OCC2_LDS>
+static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
+{
+    dim3 grid((unsigned)(p.chunk * 8)), block(256);
+    size_t lds = (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes : 0;
+    hipLaunchKernelGGL((k_shade<TRAV, OCC2_LDS>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+static int effective_traversal(int t)
+{
+    if (t == VRT_TRAVERSAL_DENSE) return VRT_TRAVERSAL_DENSE;
+    return VRT_TRAVERSAL_BITMASK;   // AUTO / BITMASK / JUMP
+}
+
+hipError_t launch_primary(const GeomParams& p, hipStream_t s)
+{
+    int t = effective_traversal((int)p.st.traversal);
+    if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
+    if (p.occ2_in_lds) return launch_primary_t<VRT_TRAVERSAL_BITMASK, true>(p, s);
+    return launch_primary_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
+}
+
+hipError_t launch_shade(const GeomParams& p, hipStream_t s)
+{
+    int t = effective_traversal((int)p.st.traversal);
+    if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
+    if (p.occ2_in_lds) return launch_shade_t<VRT_TRAVERSAL_BITMASK, true>(p, s);
+    return launch_shade_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
+}
+
+const char* primary_kernel_name(int traversal, int fused, int occ2_lds)
+{
+    int t = effective_traversal(traversal);
+    if (t == VRT_TRAVERSAL_DENSE) return fused ? "k_primary<dense,fused>" : "k_primary<dense>";
+    if (occ2_lds) return fused ? "k_primary<bitmask,lds,fused>" : "k_primary<bitmask,lds>";
+    return fused ? "k_primary<bitmask,l2,fused>" : "k_primary<bitmask,l2>";
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: a-trous denoiser pass
+// ---------------------------------------------------------------------------------------------
+
+struct Guides { float c[4], n[4], p[4]; };
+
+__device__ __forceinline__ void texel_guides(const DenoiseParams& P, int x, int y, Guides& g)
+{
+    x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+    y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+    size_t i = (size_t)y * (size_t)P.W + (size_t)x;
+    uchar4 c = reinterpret_cast<const uchar4*>(P.color_in)[i];
+    char4 n = reinterpret_cast<const char4*>(P.normal)[i];
+    float4 p = reinterpret_cast<const float4*>(P.position)[i];
+    g.c[0] = (float)c.x / 255.0f; g.c[1] = (float)c.y / 255.0f; g.c[2] = (float)c.z / 255.0f; g.c[3] = (float)c.w / 255.0f;
+    g.n[0] = fmaxf((float)n.x / 127.0f, -1.0f); g.n[1] = fmaxf((float)n.y / 127.0f, -1.0f);
+    g.n[2] = fmaxf((float)n.z / 127.0f, -1.0f); g.n[3] = fmaxf((float)n.w / 127.0f, -1.0f);
+    g.p[0] = p.x; g.p[1] = p.y; g.p[2] = p.z; g.p[3] = p.w;
+}
+
+__device__ __forceinline__ void sample_guides(const DenoiseParams& P, int px, int py, float ox, float oy, Guides& g)
+{
+    if (ox == floorf(ox) && oy == floorf(oy)) { texel_guides(P, px + (int)ox, py + (int)oy, g); return; }
+    float fx = ((float)px + 0.5f + ox) - 0.5f, fy = ((float)py + 0.5f + oy) - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float tx = fx - x0f, ty = fy - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    Guides g00, g10, g01, g11;
+    texel_guides(P, x0, y0, g00); texel_guides(P, x0 + 1, y0, g10);
+    texel_guides(P, x0, y0 + 1, g01); texel_guides(P, x0 + 1, y0 + 1, g11);
+    for (int k = 0; k < 4; k++) {
+        float a, b;
+        a = g00.c[k] + tx * (g10.c[k] - g00.c[k]); b = g01.c[k] + tx * (g11.c[k] - g01.c[k]); g.c[k] = a + ty * (b - a);
+        a = g00.n[k] + tx * (g10.n[k] - g00.n[k]); b = g01.n[k] + tx * (g11.n[k] - g01.n[k]); g.n[k] = a + ty * (b - a);
+        a = g00.p[k] + tx * (g10.p[k] - g00.p[k]); b = g01.p[k] + tx * (g11.p[k] - g01.p[k]); g.p[k] = a + ty * (b - a);
+    }
+}
+
+__device__ __forceinline__ float dist2_4(const float* a, const float* b)
+{
+    float t0 = a[0] - b[0], t1 = a[1] - b[1], t2 = a[2] - b[2], t3 = a[3] - b[3];
+    return ((t0 * t0 + t1 * t1) + t2 * t2) + t3 * t3;
+}
+
+// Row mapping shared by the denoiser and the strip copy kernels: local row index -> frame row.
+__device__ __forceinline__ int strip_row(const ShardMap& sh, int extend, int r, int H)
+{
+    int per = sh.strip_rows + 2 * extend;
+    int k = r / per, j = r % per;
+    int g = k * sh.nranks + sh.rank;
+    int y = g * sh.strip_rows - extend + j;
+    int end = (g + 1) * sh.strip_rows; if (end > H) end = H;
+    if (y < 0 || y >= end + extend || y >= H) return -1;
+    return y;
+}
+
+// denoiser.frag:38-73.  One wave = 64 consecutive pixels of one row (coalesced 256 B / 1 KiB accesses).
+__global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
+{
+    int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int py = strip_row(P.sh, P.extend, r, P.H);
+    if (py < 0 || px >= P.W) return;
+
+    float kern[9], offx[9], offy[9];
+    int ntaps;
+    if (P.mode == VRT_DENOISE_AS_SHIPPED) {
+        ntaps = 3;
+        kern[0] = kGauss2; offx[0] = -1.0f; offy[0] = -1.0f;
+        kern[1] = kGauss0; offx[1] = 1.0f;  offy[1] = -1.0f;
+        kern[2] = kGauss2; offx[2] = 0.0f;  offy[2] = 0.0f;
+    } else {
+        ntaps = 9;
+        for (int i = 0, y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++, i++) {
+                offx[i] = (float)x; offy[i] = (float)y;
+                int r2 = x * x + y * y;
+                kern[i] = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2);
+            }
+    }
+    float sw = P.step_width;
+    Guides s, o;
+    texel_guides(P, px, py, s);
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float total = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        if (i >= ntaps) break;
+        sample_guides(P, px, py, offx[i] * sw, offy[i] * sw, o);
+        float d2 = dist2_4(s.c, o.c);
+        float cw = fminf(exp_spec((-d2) / P.phi_color), 1.0f);
+        d2 = fmaxf(dist2_4(s.n, o.n) / (sw * sw), 0.0f);
+        float nw = fminf(exp_spec((-d2) / P.phi_normal), 1.0f);
+        d2 = dist2_4(s.p, o.p);
+        float pw = fminf(exp_spec((-d2) / P.phi_pos), 1.0f);
+        float w = (cw * nw) * pw;
+        for (int k = 0; k < 4; k++) sum[k] += (o.c[k] * w) * kern[i];
+        total += w * kern[i];
+    }
+    uchar4 out;
+    out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
+    out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
+    reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
+}
+
+hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
+{
+    int rows = p.sh.n_local_strips * (p.sh.strip_rows + 2 * p.extend);
+    dim3 grid((unsigned)((p.W + 63) / 64), (unsigned)((rows + 3) / 4)), block(256);
+    hipLaunchKernelGGL(k_denoise, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// strip pack / unpack (multi-GPU gather + halo exchange)
+// ---------------------------------------------------------------------------------------------
+
+// One workgroup per packed row.  halo == 0: all owned rows in order.  halo > 0: the first (dir < 0) or
+// last (dir > 0) `halo` rows of every owned strip.
+__global__ __launch_bounds__(256) void k_rows(const RowsParams P)
+{
+    int r = blockIdx.x;
+    int y;
+    if (P.halo == 0) {
+        y = strip_row(P.sh, 0, r, P.H);
+    } else {
+        int k = r / P.halo, j = r % P.halo;
+        int g = k * P.sh.nranks + P.sh.rank;
+        int beg = g * P.sh.strip_rows;
+        int end = beg + P.sh.strip_rows; if (end > P.H) end = P.H;
+        y = (P.dir < 0) ? beg + j : end - P.halo + j;
+        if (y < beg || y >= end) y = -1;
+    }
+    size_t row_bytes = (size_t)P.W * (size_t)P.bpp;
+    const uint8_t* src; uint8_t* dst;
+    if (y < 0) {
+        if (P.unpack) return;
+        // rows that do not exist (partial last strip): zero-fill the packed slot
+        dst = P.dst + (size_t)r * row_bytes;
+        for (size_t i = threadIdx.x; i < row_bytes; i += blockDim.x) dst[i] = 0;
+        return;
+    }
+    if (P.unpack) { src = P.src + (size_t)r * row_bytes; dst = P.dst + (size_t)y * row_bytes; }
+    else          { src = P.src + (size_t)y * row_bytes; dst = P.dst + (size_t)r * row_bytes; }
+    if ((row_bytes & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (size_t i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) d4[i] = s4[i];
+    } else {
+        for (size_t i = threadIdx.x; i < row_bytes; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+hipError_t launch_rows(const RowsParams& p, int rows_total, hipStream_t s)
+{
+    if (rows_total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rows, dim3((unsigned)rows_total), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+} // namespace vrt

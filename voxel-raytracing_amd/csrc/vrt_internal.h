@@ -1,0 +1,78 @@
+// vrt_internal.h -- structures shared between the C-ABI layer (vrt_api.cpp) and the HIP kernels
+// (vrt_device.hip).  Not part of the public interface.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vrt.h"
+
+namespace vrt {
+
+// Device view of a scene.  Layout in HBM (all hipMalloc'd, read-only during rendering):
+//   vox   W*H*D bytes, index x + y*W + z*W*H   (the reference's Texture3D upload order)
+//   occ1  one u64 per 4^3 voxels  : bit (x&3) | (y&3)<<2 | (z&3)<<4 set <=> voxel != 0      [n1x*n1y*n1z]
+//   occ2  one u64 per 16^3 voxels : bit over the 4x4x4 occ1 words, set <=> word != 0        [n2x*n2y*n2z]
+//   occ3  one u64 per 64^3 voxels : same over occ2                                           [n3x*n3y*n3z]
+struct DevScene {
+    const uint8_t*  vox;
+    const uint64_t* occ1;
+    const uint64_t* occ2;
+    const uint64_t* occ3;
+    int32_t W, H, D;
+    int32_t n1x, n1y, n1z;
+    int32_t n2x, n2y, n2z;
+    int32_t n3x, n3y, n3z;
+    const vrt_material* palette;
+    const float*   sky;   uint32_t sky_w, sky_h;
+    const uint8_t* noise; uint32_t noise_w, noise_h;
+};
+
+struct ShardMap {
+    int32_t rank, nranks, strip_rows;   // strip_rows multiple of 16
+    int32_t n_local_strips;
+    int32_t tiles_per_strip;            // strip_rows / 16
+};
+
+struct GeomParams {
+    DevScene   sc;
+    vrt_push   pc;
+    vrt_settings st;
+    vrt_frame  fr;
+    ShardMap   sh;
+    int32_t    tiles_x, tiles_y_local, total_tiles, chunk;  // chunk = tiles per XCD slot
+    uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)
+    int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled)
+    int32_t    occ2_in_lds;    // 1: stage occ2 into LDS, 0: read it through L2
+    uint32_t   occ2_bytes;
+};
+
+struct DenoiseParams {
+    const uint8_t* color_in;
+    const int8_t*  normal;
+    const float*   position;
+    uint8_t*       color_out;
+    int32_t W, H;
+    float phi_color, phi_normal, phi_pos, step_width;
+    int32_t mode;
+    int32_t extend;            // rows beyond each owned strip that this pass must also produce
+    ShardMap sh;
+};
+
+struct RowsParams {
+    const uint8_t* src; uint8_t* dst;
+    int32_t W, H, bpp;
+    ShardMap sh;
+    int32_t halo, dir, unpack;
+};
+
+// launchers (vrt_device.hip)
+hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_t* occ1, uint64_t* occ2,
+                                uint64_t* occ3, hipStream_t s);
+hipError_t launch_primary(const GeomParams& p, hipStream_t s);
+hipError_t launch_shade(const GeomParams& p, hipStream_t s);
+hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s);
+hipError_t launch_rows(const RowsParams& p, int rows_total, hipStream_t s);
+const char* primary_kernel_name(int traversal, int fused, int occ2_lds);
+
+} // namespace vrt

@@ -1,0 +1,204 @@
+"""Screen-tile sharding of a frame over the GPUs of one node (no reference analogue; BASELINE north_star).
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" on CPU for the tests).
+The frame is cut into horizontal strips of `strip_rows` rows; strip s belongs to rank s % nranks
+(interleaving balances sky against geometry).  The volume, palette, sky and noise are replicated.  The only
+data-path collective is ONE gather of the packed RGBA8 strips to rank 0 per step; the sharded denoiser adds
+a ring-neighbour exchange of `halo` guide rows (strip s needs rows of strips s-1 and s+1, which live on
+ranks r-1 and r+1).
+
+The row maps here are the host mirror of vrt_pack_rows / vrt_pack_halo (csrc/vrt_device.hip: k_rows); the
+CPU tests check both against each other.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+def default_strip_rows(H: int, nranks: int) -> int:
+    """16-row strips (one tile row) unless that leaves a rank without work."""
+    return 16
+
+
+def n_strips(H: int, strip_rows: int) -> int:
+    return (H + strip_rows - 1) // strip_rows
+
+
+def max_local_strips(H: int, nranks: int, strip_rows: int) -> int:
+    return (n_strips(H, strip_rows) + nranks - 1) // nranks
+
+
+def packed_rows(H: int, nranks: int, strip_rows: int) -> int:
+    """Rows in a rank's packed buffer (identical on every rank; short ranks zero-pad)."""
+    if nranks <= 1:
+        return H
+    return max_local_strips(H, nranks, strip_rows) * strip_rows
+
+
+def packed_row_map(H: int, rank: int, nranks: int, strip_rows: int) -> np.ndarray:
+    """packed row index -> frame row (or -1 for padding)."""
+    if nranks <= 1:
+        return np.arange(H, dtype=np.int64)
+    out = np.full(packed_rows(H, nranks, strip_rows), -1, dtype=np.int64)
+    for k in range(max_local_strips(H, nranks, strip_rows)):
+        g = k * nranks + rank
+        beg, end = g * strip_rows, min(H, (g + 1) * strip_rows)
+        if beg < H:
+            out[k * strip_rows:k * strip_rows + (end - beg)] = np.arange(beg, end)
+    return out
+
+
+def owned_rows(H: int, rank: int, nranks: int, strip_rows: int) -> np.ndarray:
+    m = packed_row_map(H, rank, nranks, strip_rows)
+    return m[m >= 0]
+
+
+def halo_row_map(H: int, rank: int, nranks: int, strip_rows: int, halo: int, direction: int) -> np.ndarray:
+    """Rows of vrt_pack_halo: first (direction -1) / last (+1) `halo` rows of every strip `rank` owns."""
+    out = np.full(max_local_strips(H, nranks, strip_rows) * halo, -1, dtype=np.int64)
+    for k in range(max_local_strips(H, nranks, strip_rows)):
+        g = k * nranks + rank
+        beg, end = g * strip_rows, min(H, (g + 1) * strip_rows)
+        for j in range(halo):
+            y = beg + j if direction < 0 else end - halo + j
+            if beg <= y < end:
+                out[k * halo + j] = y
+    return out
+
+
+def pack_np(full: np.ndarray, row_map: np.ndarray) -> np.ndarray:
+    out = np.zeros((len(row_map),) + full.shape[1:], dtype=full.dtype)
+    ok = row_map >= 0
+    out[ok] = full[row_map[ok]]
+    return out
+
+
+def unpack_np(packed: np.ndarray, full: np.ndarray, row_map: np.ndarray) -> None:
+    ok = row_map >= 0
+    full[row_map[ok]] = packed[ok]
+
+
+# ---- collectives -----------------------------------------------------------------------------------
+
+def gather_packed(packed, dst: int = 0, group=None):
+    """One collective per step: gather every rank's packed strips on `dst`.  Returns the list of per-rank
+    tensors on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return [packed]
+    if rank == dst:
+        bufs = [torch.empty_like(packed) for _ in range(world)]
+        dist.gather(packed, gather_list=bufs, dst=dst, group=group)
+        return bufs
+    dist.gather(packed, gather_list=None, dst=dst, group=group)
+    return None
+
+
+def exchange_halo(send_up, send_down, group=None):
+    """Ring-neighbour exchange.  send_up (first rows of my strips) goes to rank-1, send_down (last rows) to
+    rank+1.  Returns (from_below, from_above): what rank+1 / rank-1 sent me."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    up, down = (rank - 1) % world, (rank + 1) % world
+    from_below = torch.empty_like(send_up)
+    from_above = torch.empty_like(send_down)
+    if world == 1:
+        from_below.copy_(send_up); from_above.copy_(send_down)
+        return from_below, from_above
+    ops = [dist.P2POp(dist.isend, send_up, up, group), dist.P2POp(dist.irecv, from_below, down, group),
+           dist.P2POp(dist.isend, send_down, down, group), dist.P2POp(dist.irecv, from_above, up, group)]
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+    return from_below, from_above
+
+
+# ---- device-side sharded frame -----------------------------------------------------------------------
+
+class ShardedFrame:
+    """Per-rank driver: render owned strips, (optionally) exchange halos + denoise, gather RGBA8 on rank 0."""
+
+    def __init__(self, renderer, rank: int, nranks: int, strip_rows: int = None, group=None):
+        import torch
+        self.r = renderer
+        self.rank, self.nranks, self.group = int(rank), int(nranks), group
+        W, H = renderer.settings.renderResolution()
+        self.W, self.H = W, H
+        self.strip_rows = strip_rows or default_strip_rows(H, nranks)
+        self.shard = _capi.Shard(self.rank, self.nranks, self.strip_rows) if nranks > 1 else None
+        dev = renderer.engine.torch_device
+        self.prow = packed_rows(H, nranks, self.strip_rows)
+        self.packed = torch.zeros((self.prow, W, 4), dtype=torch.uint8, device=dev)
+        self.final = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+        self._halo_bufs = {}
+
+    def _lib(self):
+        return _capi.lib()
+
+    def _halo_exchange(self, gb):
+        """Fill the guide rows just outside my strips from the ring neighbours (color, normal, position)."""
+        import torch
+        l, ctx = self._lib(), self.r.engine.ctx
+        ds = self.r.settings.denoiser_to_c()
+        halo = l.vrt_denoise_halo_rows(C.byref(ds))
+        if halo <= 0 or self.nranks <= 1:
+            return
+        if halo > self.strip_rows:
+            raise ValueError(f"denoiser halo ({halo} rows) exceeds strip_rows ({self.strip_rows}); use larger strips")
+        mls = max_local_strips(self.H, self.nranks, self.strip_rows)
+        up_rank, down_rank = (self.rank - 1) % self.nranks, (self.rank + 1) % self.nranks
+        for name, bpp in (("color8", 4), ("normal8", 4), ("position", 16)):
+            full = gb.planes[name]
+            key = (name, halo)
+            if key not in self._halo_bufs:
+                mk = lambda: torch.zeros((mls * halo, self.W, bpp), dtype=torch.uint8, device=full.device)
+                self._halo_bufs[key] = (mk(), mk())
+            s_up, s_down = self._halo_bufs[key]
+            _capi.check(l.vrt_pack_halo(ctx, full.data_ptr(), s_up.data_ptr(), self.W, self.H, bpp, C.byref(self.shard), halo, -1))
+            _capi.check(l.vrt_pack_halo(ctx, full.data_ptr(), s_down.data_ptr(), self.W, self.H, bpp, C.byref(self.shard), halo, 1))
+            from_below, from_above = exchange_halo(s_up, s_down, self.group)
+            sh_below = _capi.Shard(down_rank, self.nranks, self.strip_rows)   # sender of from_below
+            sh_above = _capi.Shard(up_rank, self.nranks, self.strip_rows)
+            _capi.check(l.vrt_unpack_halo(ctx, from_below.data_ptr(), full.data_ptr(), self.W, self.H, bpp, C.byref(sh_below), halo, -1))
+            _capi.check(l.vrt_unpack_halo(ctx, from_above.data_ptr(), full.data_ptr(), self.W, self.H, bpp, C.byref(sh_above), halo, 1))
+
+    def render_local(self):
+        """Trace (and denoise) the rows this rank owns; returns the full-frame RGBA8 plane (own rows valid)."""
+        r = self.r
+        push = r.push_constants()
+        gb = r._geometryStage.record(push, self.shard)
+        r.gBuffer = gb
+        color = gb.color
+        if r.settings.denoiserSettings.enable:
+            self._halo_exchange(gb)
+            color = r._denoiserStage.record(gb.color, gb.normal, gb.position, self.shard)
+        return color
+
+    def pack(self, color_full):
+        l, ctx = self._lib(), self.r.engine.ctx
+        if self.nranks <= 1:
+            return color_full
+        _capi.check(l.vrt_pack_rows(ctx, color_full.data_ptr(), self.packed.data_ptr(), self.W, self.H, 4, C.byref(self.shard)))
+        return self.packed
+
+    def gather(self, packed):
+        """RCCL gather of the packed strips to rank 0 and de-interleave there.  Returns the final image on rank 0."""
+        l, ctx = self._lib(), self.r.engine.ctx
+        if self.nranks <= 1:
+            return packed
+        bufs = gather_packed(packed, 0, self.group)
+        if self.rank != 0:
+            return None
+        for src, b in enumerate(bufs):
+            sh = _capi.Shard(src, self.nranks, self.strip_rows)
+            _capi.check(l.vrt_unpack_rows(ctx, b.data_ptr(), self.final.data_ptr(), self.W, self.H, 4, C.byref(sh)))
+        return self.final
+
+    def step(self):
+        return self.gather(self.pack(self.render_local()))
