@@ -118,7 +118,9 @@ typedef struct vrt_shard {
 /* Engine::init (engine.cpp:14): selects HIP device `device`, creates the context stream. */
 int  vrt_ctx_create(int device, vrt_ctx** out);
 void vrt_ctx_destroy(vrt_ctx* ctx);                         /* Engine::destroy */
-/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+/* Adopt an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) in place of the
+ * context's own stream.  NULL is a valid handle: the HIP null (legacy default) stream, which is what
+ * torch's default stream is. */
 int  vrt_ctx_set_stream(vrt_ctx* ctx, void* hip_stream);
 int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle(), engine.cpp:351 */
 const char* vrt_last_error(void);
@@ -209,8 +211,9 @@ int  vrt_unpack_rows(vrt_ctx* ctx, const void* packed, void* full, int32_t W, in
 /* Pack / unpack the halo rows exchanged with the ring neighbours before a sharded denoise:
  * dir = -1: the first `halo` rows of every owned strip (sent to the rank owning the strip above),
  * dir = +1: the last `halo` rows of every owned strip (sent to the rank owning the strip below).
- * On unpack the rows land just outside the owned strips of the RECEIVING rank
- * (dir = -1 payload came from below => written below each owned strip; +1 => above). */
+ * vrt_unpack_halo takes the SENDER's shard and the same dir: the rows are written back at their true
+ * frame positions in the receiver's full-frame plane (i.e. just outside the receiver's own strips).
+ * vrt_unpack_rows likewise takes the shard of the rank that packed the buffer. */
 int  vrt_pack_halo(vrt_ctx* ctx, const void* full, void* packed, int32_t W, int32_t H,
                    int32_t bytes_per_px, const vrt_shard* shard, int32_t halo, int32_t dir);
 int  vrt_unpack_halo(vrt_ctx* ctx, const void* packed, void* full, int32_t W, int32_t H,

@@ -108,6 +108,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                               f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            # torch ships its own copy of the HIP runtime; it has to be the one the process loads first,
+            # otherwise torch cannot see the GPU after libvrt_hip.so initialised /opt/rocm's copy.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)          # AttributeError if the library does not export it

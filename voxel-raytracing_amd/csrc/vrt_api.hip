@@ -96,8 +96,8 @@ int vrt_ctx_set_stream(vrt_ctx* c, void* hip_stream)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
-    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    c->stream = (hipStream_t)hip_stream;      // NULL is a valid handle: the HIP null (legacy default) stream
+    c->own_stream = false;
     c->have_geo = c->have_den = false;
     return VRT_OK;
 }
@@ -405,7 +405,7 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     p.tiles_x = ceil_div(W, 16);
     p.tiles_y_local = p.sh.n_local_strips * p.sh.tiles_per_strip;
     p.total_tiles = p.tiles_x * p.tiles_y_local;
-    p.chunk = ceil_div(p.total_tiles, 8);
+    p.chunk = p.tiles_x * ceil_div(p.tiles_y_local, 8);      // workgroups per XCD slot (tile rows are dealt round-robin)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : 0;
     p.occ2_bytes = s->occ2_bytes;
     p.occ2_in_lds = (s->occ2_bytes <= 65536) ? 1 : 0;

@@ -344,9 +344,12 @@ __device__ f3 color_main_ray(const GeomParams& P, const uint64_t* locc2, PixCtx&
 __device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y0)
 {
     int b = blockIdx.x;
-    int t = (b & 7) * P.chunk + (b >> 3);
-    if ((b >> 3) >= P.chunk || t >= P.total_tiles) return false;
-    int tx = t % P.tiles_x, ty = t / P.tiles_x;
+    // XCD slot (b & 7) owns tile rows ty with ty % 8 == slot: every XCD gets an even sample of sky and
+    // geometry (a contiguous band per XCD leaves the XCDs that drew the sky idle), while the tiles of one
+    // row -- which walk neighbouring volume cells -- still share that XCD's L2.
+    int slot = b & 7, idx = b >> 3;
+    int tx = idx % P.tiles_x, ty = (idx / P.tiles_x) * 8 + slot;
+    if (ty >= P.tiles_y_local) return false;
     int strip_local = ty / P.sh.tiles_per_strip, within = ty % P.sh.tiles_per_strip;
     x0 = tx * 16;
     y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + within * 16;

@@ -190,6 +190,8 @@ class Engine:
     def __init__(self, device: int = 0, use_torch_stream: bool = True):
         l = lib()
         self.device = int(device)
+        if use_torch_stream:
+            _torch().cuda.init()                 # torch's HIP runtime first (see _capi.lib)
         self._ctx = C.c_void_p()
         check(l.vrt_ctx_create(self.device, C.byref(self._ctx)))
         self.torch_device = None
