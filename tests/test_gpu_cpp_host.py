@@ -1,0 +1,60 @@
+"""The C++ host mirror (voxel-raytracing_amd/host/voxels.hpp + app.cpp) drives the same C-ABI: its image must
+equal the oracle's for the push constants it computed itself (its CameraController is C++ libm, so the push
+block is taken from the app rather than recomputed in Python)."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import metallic_palette
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+APP = os.path.join(ROOT, "voxel-raytracing_amd", "host", "vrt_app")
+
+
+def _write_dense(path, vol, pal, sky, noise):
+    D, H, W = vol.shape
+    pal8 = np.zeros((256, 8), np.float32); pal8[:, :5] = pal
+    with open(path, "wb") as f:
+        f.write(b"VRTD" + struct.pack("<III", W, H, D)); f.write(vol.tobytes()); f.write(pal8.tobytes())
+        f.write(struct.pack("<II", sky.shape[1], sky.shape[0])); f.write(sky.astype(np.float32).tobytes())
+        f.write(struct.pack("<II", noise.shape[1], noise.shape[0])); f.write(noise.astype(np.uint8).tobytes())
+
+
+def test_cpp_app_matches_oracle(vrt, oracle, tmp_path):
+    assert os.path.exists(APP), "build with __graft_entry__.build()"
+    vol = vrt.synthetic.floating_cubes(48, seed=6, count=60)
+    pal = metallic_palette(vrt)
+    sky, noise = vrt.synthetic.sky_gradient(64, 32), vrt.synthetic.blue_noise_standin(64)
+    dense = tmp_path / "scene.vrtd"
+    _write_dense(dense, vol, pal, sky, noise)
+    raw, pushf = tmp_path / "out.rgba", tmp_path / "push.bin"
+    r = subprocess.run([APP, "--dense", str(dense), "--width", "320", "--height", "180", "--pos", "24.3", "24.2", "-40",
+                        "--raw", str(raw), "--dump-push", str(pushf), "--out", str(tmp_path / "out.ppm")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    push = oracle.Push.from_buffer_copy(pushf.read_bytes())
+    W, H = push.screen_size[0], push.screen_size[1]
+    assert (W, H) == (188, 105)                       # default FSR "Balanced" render scale of 320x180
+    st = vrt.VoxelRenderSettings(targetResolution=(320, 180))
+    exp = oracle.render(oracle.OracleScene(vol, pal, sky=sky, noise=noise), push, oracle.params_from(st.to_c()), nthreads=8)
+    eimg = oracle.denoise(exp["color8"], exp["normal8"], exp["position"])
+    got = np.frombuffer(raw.read_bytes(), np.uint8).reshape(H, W, 4)
+    assert (got == eimg).all()
+    assert (tmp_path / "out.ppm").read_bytes().startswith(b"P6\n188 105\n255\n")
+
+
+def test_cpp_app_error_behaviour(tmp_path):
+    # reference: exceptions bubble to run(), are printed, exit code EXIT_FAILURE (app.cpp:21-25)
+    r = subprocess.run([APP, "--vox", str(tmp_path / "missing.vox")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Failed to read voxel scene" in r.stderr
+    gold = os.path.join(ROOT, "tests", "golden", "vox_err_bad_magic.vox")
+    r = subprocess.run([APP, "--vox", gold], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Could not parse voxel scene" in r.stderr
+    r = subprocess.run([APP, "--vox", os.path.join(ROOT, "tests", "golden", "vox_multi.vox"), "--width", "64", "--height", "48",
+                        "--primary-only", "--no-denoise", "--no-fsr", "--raw", str(tmp_path / "o.rgba")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and os.path.getsize(tmp_path / "o.rgba") == 64 * 48 * 4

@@ -1,0 +1,244 @@
+// voxels.hpp -- C++17 host side above the C-ABI (include/vrt.h), mirroring the reference's object surface for
+// the hot path: same class names, member names, argument meaning and error behaviour (std::runtime_error with
+// the reference's messages).  Header-only; link with libvrt_hip.so.  No Vulkan, no HIP headers needed.
+//
+//   VoxelRenderSettings (+Fsr/Denoiser/AmbientOcclusion/LightSettings)  source/voxels/voxel_render_settings.hpp:6-59
+//   CameraController                                                   source/voxels/resource/camera_controller.cpp:15-44
+//   VoxelScene                                                         source/voxels/resource/voxel_scene.hpp:18-34
+//   GeometryBuffer / GeometryStage                                     source/voxels/stages/geometry_stage.hpp:19-53
+//   DenoiserStage                                                      source/voxels/stages/denoiser_stage.hpp:22-47
+//   VoxelRenderer                                                      source/voxels/voxel_renderer.hpp:17-38
+//   Engine                                                             source/engine/engine.hpp:71-76 (device + stream only)
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vrt.h"
+
+namespace vrt_host {
+
+inline void check(int rc)
+{
+    if (rc != VRT_OK) throw std::runtime_error(vrt_last_error());
+}
+
+struct vec3 { float x = 0, y = 0, z = 0; };
+inline vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline vec3 cross(vec3 a, vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline vec3 normalize(vec3 a) { float l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return {a.x / l, a.y / l, a.z / l}; }
+
+// ---- settings (voxel_render_settings.hpp) -------------------------------------------------------------
+enum class FsrScaling : uint32_t { NONE = 10, QUALITY = 15, BALANCED = 17, PERFORMANCE = 20, ULTRA_PERFORMANCE = 30 };
+struct FsrSettings { bool enable = true; FsrScaling scaling = FsrScaling::BALANCED; };
+struct DenoiserSettings {
+    bool enable = true; int iterations = 2; float phiColor0 = 20.4f; float phiNormal0 = 1E-2f; float phiPos0 = 1E-1f;
+    float stepWidth = 2.0f; int mode = VRT_DENOISE_CANONICAL;
+};
+struct AmbientOcclusionSettings { int numSamples = 4; float intensity = 1.0f; };
+struct LightSettings { vec3 direction = normalize({1.0f, 1.0f, 1.0f}); std::array<float, 4> color{1, 1, 1, 1}; float intensity = 1.0f; };
+struct TraceSettings {   // voxel_volume.frag:68-69,219 promoted to runtime knobs
+    uint32_t maxRaySteps = 512, aoSteps = 64, maxReflections = 5; bool shadows = true; uint32_t traversal = VRT_TRAVERSAL_AUTO;
+};
+
+class VoxelRenderSettings {
+public:
+    std::array<uint32_t, 2> targetResolution{1920, 1080};
+    FsrSettings fsrSetttings{};            // (sic)
+    DenoiserSettings denoiserSettings{};
+    AmbientOcclusionSettings occlusionSettings{};
+    LightSettings lightSettings{};
+    TraceSettings traceSettings{};
+    std::string voxPath = "../resource/treehouse.vox";
+    std::string skyboxPath = "../resource/rustig_koppie.hdr";
+
+    std::array<uint32_t, 2> renderResolution() const     // voxel_render_settings.cpp:3-13
+    {
+        if (!fsrSetttings.enable) return targetResolution;
+        auto scale = [&](uint32_t dim) { return static_cast<uint32_t>((10.0f / static_cast<uint32_t>(fsrSetttings.scaling)) * dim); };
+        return {scale(targetResolution[0]), scale(targetResolution[1])};
+    }
+    vrt_settings toC() const                             // geometry_stage.cpp:135-145
+    {
+        vrt_settings s{};
+        s.ao_samples = (uint32_t)occlusionSettings.numSamples; s.ambient_intensity = occlusionSettings.intensity;
+        s.light_dir[0] = lightSettings.direction.x; s.light_dir[1] = lightSettings.direction.y; s.light_dir[2] = lightSettings.direction.z;
+        s.light_intensity = lightSettings.intensity;
+        for (int i = 0; i < 4; i++) s.light_color[i] = lightSettings.color[i];
+        s.max_steps = traceSettings.maxRaySteps; s.ao_steps = traceSettings.aoSteps; s.max_bounces = traceSettings.maxReflections;
+        s.shadows = traceSettings.shadows ? 1u : 0u; s.traversal = traceSettings.traversal; s.flags = 0;
+        return s;
+    }
+    vrt_denoiser_settings denoiserToC() const
+    {
+        return {denoiserSettings.iterations, denoiserSettings.phiColor0, denoiserSettings.phiNormal0, denoiserSettings.phiPos0,
+                denoiserSettings.stepWidth, denoiserSettings.mode};
+    }
+};
+
+// ---- camera (camera_controller.cpp) -------------------------------------------------------------------
+class CameraController {
+public:
+    vec3 position, direction, right, up, normalDir;
+    float yaw, pitch, focalLength;
+    explicit CameraController(vec3 position = {8, 8, -50}, float yaw = 90.0f, float pitch = 0.0f,
+                              float focalLength = static_cast<float>(1 / std::tan((55.0 / 2) * 3.14159265358979323846 / 180)))
+        : position(position), yaw(yaw), pitch(pitch), focalLength(focalLength) { updateDirectionVectors(); }
+    void updateDirectionVectors()                         // :15-28
+    {
+        const vec3 worldUp{0.0f, -1.0f, 0.0f};
+        const float ry = yaw * 0.01745329251994329576923690768489f, rp = pitch * 0.01745329251994329576923690768489f;
+        normalDir = normalize({std::cos(ry) * std::cos(rp), std::sin(rp), std::sin(ry) * std::cos(rp)});
+        right = normalize(cross(normalDir, worldUp));
+        up = normalize(cross(right, normalDir));
+        direction = normalDir * focalLength;
+    }
+    void update(float delta, float forward = 0.0f, float strafe = 0.0f)   // :30-44, keys replaced by scripted axes
+    {
+        const float cameraSpeed = 50.0f;
+        position = position + normalDir * (cameraSpeed * delta * forward) + right * (cameraSpeed * delta * strafe);
+        updateDirectionVectors();
+    }
+};
+
+// ---- engine -------------------------------------------------------------------------------------------
+class Engine {
+public:
+    explicit Engine(int device = 0) { check(vrt_ctx_create(device, &ctx)); }
+    ~Engine() { vrt_ctx_destroy(ctx); }
+    Engine(const Engine&) = delete; Engine& operator=(const Engine&) = delete;
+    void waitIdle() { check(vrt_ctx_synchronize(ctx)); }
+    vrt_ctx* ctx = nullptr;
+};
+
+template <class T> class DeviceBuffer {                   // Buffer / RenderImage storage (engine/resource/buffer.hpp)
+public:
+    DeviceBuffer(const std::shared_ptr<Engine>& e, size_t count) : engine(e), count(count)
+    {
+        void* p = nullptr; check(vrt_device_alloc(e->ctx, count * sizeof(T), &p)); ptr = static_cast<T*>(p);
+        check(vrt_memset(e->ctx, ptr, 0, count * sizeof(T)));
+    }
+    ~DeviceBuffer() { vrt_device_free(engine->ctx, ptr); }
+    DeviceBuffer(const DeviceBuffer&) = delete; DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    std::vector<T> download() const { std::vector<T> h(count); check(vrt_memcpy_d2h(engine->ctx, h.data(), ptr, count * sizeof(T))); return h; }
+private:
+    std::shared_ptr<Engine> engine;
+public:
+    size_t count;
+    T* ptr = nullptr;
+};
+
+// ---- scene --------------------------------------------------------------------------------------------
+class VoxelScene {
+public:
+    uint32_t width = 0, height = 0, depth = 0;
+    VoxelScene(const std::shared_ptr<Engine>& engine, const std::string& filename) : engine(engine)   // voxel_scene.cpp:33
+    {
+        check(vrt_scene_load_vox_file(engine->ctx, filename.c_str(), &handle)); dims();
+    }
+    VoxelScene(const std::shared_ptr<Engine>& engine, const uint8_t* voxels, uint32_t W, uint32_t H, uint32_t D, const vrt_material* palette)
+        : engine(engine) { check(vrt_scene_from_dense(engine->ctx, voxels, W, H, D, palette, &handle)); dims(); }
+    ~VoxelScene() { vrt_scene_free(engine->ctx, handle); }
+    VoxelScene(const VoxelScene&) = delete; VoxelScene& operator=(const VoxelScene&) = delete;
+    void setSkybox(const float* rgba, uint32_t w, uint32_t h) { check(vrt_scene_set_sky(engine->ctx, handle, rgba, w, h)); }
+    void setBlueNoise(const uint8_t* rgba8, uint32_t w, uint32_t h) { check(vrt_scene_set_blue_noise(engine->ctx, handle, rgba8, w, h)); }
+    vrt_scene* handle = nullptr;
+private:
+    void dims() { uint32_t d[3]; check(vrt_scene_info(handle, d)); width = d[0]; height = d[1]; depth = d[2]; }
+    std::shared_ptr<Engine> engine;
+};
+
+// ---- stages -------------------------------------------------------------------------------------------
+struct GeometryBuffer {                                   // geometry_stage.hpp:19-27
+    std::shared_ptr<DeviceBuffer<uint8_t>> color, mask; std::shared_ptr<DeviceBuffer<float>> depth, motion, position;
+    std::shared_ptr<DeviceBuffer<int8_t>> normal; uint32_t width = 0, height = 0;
+};
+
+class GeometryStage {
+public:
+    GeometryStage(const std::shared_ptr<Engine>& engine, const std::shared_ptr<VoxelRenderSettings>& settings, const std::shared_ptr<VoxelScene>& scene)
+        : engine(engine), settings(settings), scene(scene) {}
+    GeometryBuffer record(const vrt_push& push, const vrt_shard* shard = nullptr)     // geometry_stage.cpp:106
+    {
+        auto res = settings->renderResolution();
+        if (gb.width != res[0] || gb.height != res[1]) {                              // RENDER_RESIZE recreation (:19-45)
+            size_t n = (size_t)res[0] * res[1];
+            gb.color = std::make_shared<DeviceBuffer<uint8_t>>(engine, n * 4); gb.mask = std::make_shared<DeviceBuffer<uint8_t>>(engine, n);
+            gb.depth = std::make_shared<DeviceBuffer<float>>(engine, n); gb.motion = std::make_shared<DeviceBuffer<float>>(engine, n * 2);
+            gb.position = std::make_shared<DeviceBuffer<float>>(engine, n * 4); gb.normal = std::make_shared<DeviceBuffer<int8_t>>(engine, n * 4);
+            gb.width = res[0]; gb.height = res[1];
+        }
+        vrt_frame f{}; f.color8 = gb.color->ptr; f.depth = gb.depth->ptr; f.motion = gb.motion->ptr; f.mask8 = gb.mask->ptr;
+        f.position = gb.position->ptr; f.normal8 = gb.normal->ptr;
+        vrt_settings st = settings->toC();
+        check(vrt_render_geometry(engine->ctx, scene->handle, &push, &st, &f, shard));
+        return gb;
+    }
+private:
+    std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> settings; std::shared_ptr<VoxelScene> scene; GeometryBuffer gb;
+};
+
+class DenoiserStage {
+public:
+    DenoiserStage(const std::shared_ptr<Engine>& engine, const std::shared_ptr<VoxelRenderSettings>& settings) : engine(engine), settings(settings) {}
+    // returns the device pointer of the image holding the result (one of the ping-pong targets, or colorInput)
+    const uint8_t* record(const GeometryBuffer& g, const vrt_shard* shard = nullptr)  // denoiser_stage.cpp:156
+    {
+        size_t n = (size_t)g.width * g.height * 4;
+        if (!targets[0] || targets[0]->count != n) { targets[0] = std::make_shared<DeviceBuffer<uint8_t>>(engine, n); targets[1] = std::make_shared<DeviceBuffer<uint8_t>>(engine, n); }
+        vrt_denoiser_settings ds = settings->denoiserToC();
+        const uint8_t* result = nullptr;
+        check(vrt_denoise(engine->ctx, (int32_t)g.width, (int32_t)g.height, &ds, g.color->ptr, g.normal->ptr, g.position->ptr,
+                          targets[0]->ptr, targets[1]->ptr, shard, &result));
+        return result;
+    }
+private:
+    std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> settings; std::shared_ptr<DeviceBuffer<uint8_t>> targets[2];
+};
+
+// ---- renderer (voxel_renderer.cpp) ----------------------------------------------------------------------
+class VoxelRenderer {
+public:
+    VoxelRenderer(const std::shared_ptr<Engine>& engine, const std::shared_ptr<VoxelRenderSettings>& settings, const std::shared_ptr<VoxelScene>& scene)
+        : engine(engine), _settings(settings), _scene(scene), _camera(std::make_unique<CameraController>()),
+          _geometryStage(std::make_unique<GeometryStage>(engine, settings, scene)), _denoiserStage(std::make_unique<DenoiserStage>(engine, settings)) {}
+    CameraController& camera() { return *_camera; }
+    void update(float delta, float forward = 0.0f, float strafe = 0.0f) { _time += delta; _camera->update(delta, forward, strafe); }   // :33
+    vrt_push pushConstants() const                                                     // :72-83
+    {
+        vrt_push p{}; auto res = _settings->renderResolution();
+        p.screen_size[0] = (int32_t)res[0]; p.screen_size[1] = (int32_t)res[1];
+        p.volume_bounds[0] = _scene->width; p.volume_bounds[1] = _scene->height; p.volume_bounds[2] = _scene->depth;
+        const CameraController& c = *_camera;
+        p.cam_pos[0] = c.position.x; p.cam_pos[1] = c.position.y; p.cam_pos[2] = c.position.z; p.cam_pos[3] = 1;
+        p.cam_dir[0] = c.direction.x; p.cam_dir[1] = c.direction.y; p.cam_dir[2] = c.direction.z;
+        p.cam_up[0] = c.up.x; p.cam_up[1] = c.up.y; p.cam_up[2] = c.up.z;
+        p.cam_right[0] = c.right.x; p.cam_right[1] = c.right.y; p.cam_right[2] = c.right.z;
+        p.frame = frameCount; p.camera_jitter[0] = jitterX; p.camera_jitter[1] = jitterY;
+        return p;
+    }
+    // recordCommands (:55-94) reduced to the hot path; returns the RGBA8 image (host copy)
+    std::vector<uint8_t> render()
+    {
+        vrt_push push = pushConstants();
+        GeometryBuffer g = _geometryStage->record(push);
+        const uint8_t* img = _settings->denoiserSettings.enable ? _denoiserStage->record(g) : g.color->ptr;
+        std::vector<uint8_t> host((size_t)g.width * g.height * 4);
+        check(vrt_memcpy_d2h(engine->ctx, host.data(), img, host.size()));
+        gBuffer = g;
+        return host;
+    }
+    uint32_t frameCount = 0; float jitterX = 0, jitterY = 0; GeometryBuffer gBuffer;
+private:
+    std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> _settings; std::shared_ptr<VoxelScene> _scene;
+    std::unique_ptr<CameraController> _camera; std::unique_ptr<GeometryStage> _geometryStage; std::unique_ptr<DenoiserStage> _denoiserStage;
+    float _time = 0;
+};
+
+} // namespace vrt_host
