@@ -173,7 +173,7 @@ def test_vox_file_load_matches_from_dense(vrt, oracle, engine, tmp_path):
     # and it renders identically to the oracle fed with the reference parser's volume
     osn = oracle.OracleScene(exp["voxels"], pal)
     res = (40, 24)
-    st = vrt.VoxelRenderSettings.primary_only(res)
+    st = vrt.VoxelRenderSettings.primary_only(res, vrt.TRAVERSAL_BITMASK)     # exact step counts (JUMP reports bounds)
     W, H, D = sc.width, sc.height, sc.depth
     push = camera_push(vrt, (W, H, D), res, pos=(W / 2 + 0.3, H / 2 + 0.1, -1.2 * D))
     stage = vrt.GeometryStage(engine, st, sc, debug_planes=True)

@@ -52,7 +52,7 @@ struct vrt_scene {
     vrt_material* palette = nullptr;
     float* sky = nullptr;
     uint8_t* noise = nullptr;
-    uint32_t occ2_bytes = 0;
+    uint32_t occ2_bytes = 0, occ3_bytes = 0;
 };
 
 extern "C" {
@@ -222,29 +222,31 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
         return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_from_dense: each dimension must be in 1..4096");
     HIPCHK(hipSetDevice(c->device));
     vrt_scene* s = new vrt_scene();
-    DevScene& d = s->d;
+    VolumeView& d = s->d.vol;
     d.W = (int)W; d.H = (int)H; d.D = (int)D;
     d.n1x = ceil_div(d.W, 4); d.n1y = ceil_div(d.H, 4); d.n1z = ceil_div(d.D, 4);
     d.n2x = ceil_div(d.n1x, 4); d.n2y = ceil_div(d.n1y, 4); d.n2z = ceil_div(d.n1z, 4);
     d.n3x = ceil_div(d.n2x, 4); d.n3y = ceil_div(d.n2y, 4); d.n3z = ceil_div(d.n2z, 4);
     size_t nvox = (size_t)W * H * D;
     size_t n1 = (size_t)d.n1x * d.n1y * d.n1z, n2 = (size_t)d.n2x * d.n2y * d.n2z, n3 = (size_t)d.n3x * d.n3y * d.n3z;
-    size_t n2pad = (n2 + 1) & ~(size_t)1;          // 16-byte multiple for the uint4 LDS staging loop
+    size_t n2pad = (n2 + 1) & ~(size_t)1;          // 16-byte multiples for the uint4 LDS staging loop
+    size_t n3pad = (n3 + 1) & ~(size_t)1;
     int rc = VRT_OK;
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
     SCHK(hipMalloc((void**)&s->vox, nvox));
     SCHK(hipMalloc((void**)&s->occ1, n1 * 8));
     SCHK(hipMalloc((void**)&s->occ2, n2pad * 8));
-    SCHK(hipMalloc((void**)&s->occ3, n3 * 8));
+    SCHK(hipMalloc((void**)&s->occ3, n3pad * 8));
     SCHK(hipMalloc((void**)&s->palette, 256 * sizeof(vrt_material)));
     SCHK(hipMemsetAsync(s->occ2, 0, n2pad * 8, c->stream));
+    SCHK(hipMemsetAsync(s->occ3, 0, n3pad * 8, c->stream));
     SCHK(hipMemcpyAsync(s->vox, voxels, nvox, hipMemcpyHostToDevice, c->stream));
     SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_build_pyramid(s->vox, d.W, d.H, d.D, s->occ1, s->occ2, s->occ3, c->stream));
     SCHK(hipStreamSynchronize(c->stream));
 #undef SCHK
-    d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.palette = s->palette;
-    s->occ2_bytes = (uint32_t)(n2pad * 8);
+    d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; s->d.palette = s->palette;
+    s->occ2_bytes = (uint32_t)(n2pad * 8); s->occ3_bytes = (uint32_t)(n3pad * 8);
     {
         const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         const uint8_t grey[4] = {128, 128, 128, 255};
@@ -306,7 +308,7 @@ int vrt_scene_load_vox_file(vrt_ctx* c, const char* path, vrt_scene** out)
 int vrt_scene_info(const vrt_scene* s, uint32_t dims[3])
 {
     if (!s || !dims) return fail(VRT_ERR_INVALID, "vrt_scene_info: NULL argument");
-    dims[0] = (uint32_t)s->d.W; dims[1] = (uint32_t)s->d.H; dims[2] = (uint32_t)s->d.D;
+    dims[0] = (uint32_t)s->d.vol.W; dims[1] = (uint32_t)s->d.vol.H; dims[2] = (uint32_t)s->d.vol.D;
     return VRT_OK;
 }
 
@@ -315,7 +317,7 @@ int vrt_scene_download(vrt_ctx* c, const vrt_scene* s, uint8_t* voxels, vrt_mate
     if (!c || !s) return fail(VRT_ERR_INVALID, "vrt_scene_download: NULL argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (voxels) HIPCHK(hipMemcpy(voxels, s->vox, (size_t)s->d.W * s->d.H * s->d.D, hipMemcpyDeviceToHost));
+    if (voxels) HIPCHK(hipMemcpy(voxels, s->vox, (size_t)s->d.vol.W * s->d.vol.H * s->d.vol.D, hipMemcpyDeviceToHost));
     if (palette) HIPCHK(hipMemcpy(palette, s->palette, 256 * sizeof(vrt_material), hipMemcpyDeviceToHost));
     return VRT_OK;
 }
@@ -391,7 +393,7 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     if (!c || !s || !push || !st || !frame) return fail(VRT_ERR_INVALID, "vrt_render_geometry: NULL argument");
     int W = push->screen_size[0], H = push->screen_size[1];
     if (W <= 0 || H <= 0 || W > 32768 || H > 32768) return fail(VRT_ERR_INVALID, "vrt_render_geometry: bad screen_size");
-    if (push->volume_bounds[0] != (uint32_t)s->d.W || push->volume_bounds[1] != (uint32_t)s->d.H || push->volume_bounds[2] != (uint32_t)s->d.D)
+    if (push->volume_bounds[0] != (uint32_t)s->d.vol.W || push->volume_bounds[1] != (uint32_t)s->d.vol.H || push->volume_bounds[2] != (uint32_t)s->d.vol.D)
         return fail(VRT_ERR_INVALID, "vrt_render_geometry: push.volume_bounds must equal the scene dimensions (voxel_renderer.cpp:74)");
     if (st->max_bounces > VRT_MAX_BOUNCES) return fail(VRT_ERR_INVALID, "vrt_render_geometry: max_bounces > VRT_MAX_BOUNCES");
     if (st->traversal > VRT_TRAVERSAL_JUMP) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
@@ -407,8 +409,8 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     p.total_tiles = p.tiles_x * p.tiles_y_local;
     p.chunk = p.tiles_x * ceil_div(p.tiles_y_local, 8);      // workgroups per XCD slot (tile rows are dealt round-robin)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : 0;
-    p.occ2_bytes = s->occ2_bytes;
-    p.occ2_in_lds = (s->occ2_bytes <= 65536) ? 1 : 0;
+    p.occ2_bytes = s->occ2_bytes; p.occ3_bytes = s->occ3_bytes;
+    p.occ_in_lds = ((size_t)s->occ2_bytes + s->occ3_bytes <= 65536) ? 1 : 0;
     if (!p.fused_shade) {
         size_t px = (size_t)W * (size_t)H;
         if (c->records_px < px) {

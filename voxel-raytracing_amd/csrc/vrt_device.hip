@@ -86,93 +86,13 @@ hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_
 // traversal
 // ---------------------------------------------------------------------------------------------
 
-struct RayInt {            // RayHitInternal, voxel_volume.frag:33-41
-    f3 pos, side, delta;
-    int sx, sy, sz;        // rayStep
-    int mx, my, mz;        // mapPos at loop exit
-    uint32_t material;
-    uint32_t mask;         // bit0..2
-    uint32_t fetches;      // iterations that sampled a voxel (voxel_volume.frag:157)
-};
-
 struct RayHit {            // RayHit, voxel_volume.frag:43-49
     uint32_t material;
     f3 pos, normal, dir;
 };
 
-// The occ1 word of 4^3 cell (cx,cy,cz): the 16^3 summary (LDS or L2) is consulted first so that empty
-// space costs no global-memory transaction at all.
-template <bool OCC2_LDS>
-__device__ __forceinline__ uint64_t fetch_cell(const DevScene& s, const uint64_t* locc2, int cx, int cy, int cz)
-{
-    int i2 = (cx >> 2) + ((cy >> 2) + (cz >> 2) * s.n2y) * s.n2x;
-    uint64_t w2 = OCC2_LDS ? locc2[i2] : s.occ2[i2];
-    uint32_t b = (uint32_t)(cx & 3) | ((uint32_t)(cy & 3) << 2) | ((uint32_t)(cz & 3) << 4);
-    if (!((w2 >> b) & 1ull)) return 0ull;
-    return s.occ1[cx + (cy + cz * s.n1y) * s.n1x];
-}
-
-// traceRayInt, voxel_volume.frag:127-174 (+ boxIntersection :109-125).
-template <int TRAV, bool OCC2_LDS>
-__device__ __forceinline__ void trace_int(const DevScene& s, const uint64_t* locc2, f3 start, f3 dir,
-                                          uint32_t maxSteps, RayInt& r)
-{
-    // boxIntersection
-    float ivx = 1.0f / dir.x, ivy = 1.0f / dir.y, ivz = 1.0f / dir.z;
-    float t1x = (-start.x) * ivx, t2x = ((float)s.W - start.x) * ivx;
-    float t1y = (-start.y) * ivy, t2y = ((float)s.H - start.y) * ivy;
-    float t1z = (-start.z) * ivz, t2z = ((float)s.D - start.z) * ivz;
-    float tnx = fminf(t1x, t2x), tny = fminf(t1y, t2y), tnz = fminf(t1z, t2z);
-    float txx = fmaxf(t1x, t2x), txy = fmaxf(t1y, t2y), txz = fmaxf(t1z, t2z);
-    float tmin = fmaxf(tnx, fmaxf(tny, tnz));
-    float tmax = fminf(txx, fminf(txy, txz));
-    f3 p = start;
-    uint32_t mask = 0;
-    if (tmin >= 0.0f && tmax >= tmin) {
-        float t = tmin + 0.1f;
-        p = mk3(start.x + t * dir.x, start.y + t * dir.y, start.z + t * dir.z);
-        mask = (uint32_t)(tnx == tmin) | ((uint32_t)(tny == tmin) << 1) | ((uint32_t)(tnz == tmin) << 2);
-    }
-    int mx = (int)floorf(p.x), my = (int)floorf(p.y), mz = (int)floorf(p.z);
-    float dx = fabsf(ivx), dy = fabsf(ivy), dz = fabsf(ivz);
-    float gx = fsign(dir.x), gy = fsign(dir.y), gz = fsign(dir.z);
-    int sx = (int)gx, sy = (int)gy, sz = (int)gz;
-    float sdx = ((gx * ((float)mx - p.x) + gx * 0.5f) + 0.5f) * dx;
-    float sdy = ((gy * ((float)my - p.y) + gy * 0.5f) + 0.5f) * dy;
-    float sdz = ((gz * ((float)mz - p.z) + gz * 0.5f) + 0.5f) * dz;
-
-    uint32_t material = 0, fetches = 0;
-    uint32_t ckey = 0xFFFFFFFFu;
-    uint64_t word = 0;
-    uint32_t i = 0;
-    for (; i < maxSteps; i++) {
-        if ((uint32_t)mx >= (uint32_t)s.W || (uint32_t)my >= (uint32_t)s.H || (uint32_t)mz >= (uint32_t)s.D) break;
-        if (TRAV == VRT_TRAVERSAL_DENSE) {
-            material = s.vox[(size_t)mx + ((size_t)my + (size_t)mz * s.H) * s.W];
-            if (material != 0) { fetches = i + 1; break; }
-        } else {
-            uint32_t key = (uint32_t)(mx >> 2) | ((uint32_t)(my >> 2) << 10) | ((uint32_t)(mz >> 2) << 20);
-            if (key != ckey) { ckey = key; word = fetch_cell<OCC2_LDS>(s, locc2, mx >> 2, my >> 2, mz >> 2); }
-            uint32_t bit = (uint32_t)(mx & 3) | ((uint32_t)(my & 3) << 2) | ((uint32_t)(mz & 3) << 4);
-            if ((word >> bit) & 1ull) {
-                material = s.vox[(size_t)mx + ((size_t)my + (size_t)mz * s.H) * s.W];
-                fetches = i + 1;
-                break;
-            }
-        }
-        bool m0 = sdx <= fminf(sdy, sdz);
-        bool m1 = sdy <= fminf(sdz, sdx);
-        bool m2 = sdz <= fminf(sdx, sdy);
-        mask = (uint32_t)m0 | ((uint32_t)m1 << 1) | ((uint32_t)m2 << 2);
-        if (m0) { sdx = sdx + dx; mx += sx; }
-        if (m1) { sdy = sdy + dy; my += sy; }
-        if (m2) { sdz = sdz + dz; mz += sz; }
-    }
-    if (material == 0) fetches = i;
-    r.pos = p; r.side = mk3(sdx, sdy, sdz); r.delta = mk3(dx, dy, dz);
-    r.sx = sx; r.sy = sy; r.sz = sz; r.mx = mx; r.my = my; r.mz = mz;
-    r.material = material; r.mask = mask; r.fetches = fetches;
-}
+// occupancy summaries as seen by a workgroup: LDS copies when they fit, the L2-resident originals otherwise
+struct Occ { const uint64_t* o2; const uint64_t* o3; };
 
 __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 {
@@ -181,11 +101,11 @@ __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 }
 
 // traceRay, voxel_volume.frag:176-196
-template <int TRAV, bool OCC2_LDS>
-__device__ __forceinline__ void trace_ray(const DevScene& s, const uint64_t* locc2, f3 start, f3 dir,
+template <int TRAV>
+__device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 start, f3 dir,
                                           uint32_t maxSteps, RayHit& h, RayInt& r)
 {
-    trace_int<TRAV, OCC2_LDS>(s, locc2, start, dir, maxSteps, r);
+    trace_int<TRAV>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
     h.material = r.material;
     h.dir = dir;
     if (r.material != 0) {
@@ -251,8 +171,8 @@ __device__ __forceinline__ f3 primary_dir(const vrt_push& pc, int px, int py)
 }
 
 // calcAmbient + isShadowed + color + colorHit, voxel_volume.frag:205-264
-template <int TRAV, bool OCC2_LDS>
-__device__ f3 color_hit(const GeomParams& P, const uint64_t* locc2, PixCtx& c, const RayHit& hit,
+template <int TRAV>
+__device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit,
                         f3 reflection, uint32_t depth)
 {
     const DevScene& s = P.sc;
@@ -269,7 +189,8 @@ __device__ f3 color_hit(const GeomParams& P, const uint64_t* locc2, PixCtx& c, c
             f3 dir = mk3(hit.normal.x + rd.x, hit.normal.y + rd.y, hit.normal.z + rd.z);
             f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
             RayInt r;
-            trace_int<TRAV, OCC2_LDS>(s, locc2, o, dir, st.ao_steps, r);
+            // AO rays have a 64-iteration budget: too short for jumps to pay, and budget ties would force re-traces
+            trace_int<(TRAV == VRT_TRAVERSAL_JUMP ? VRT_TRAVERSAL_BITMASK : TRAV)>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);
             c.fetches += r.fetches; c.rays++;
             if (r.material != 0) ambient += sample_frac;
         }
@@ -283,7 +204,7 @@ __device__ f3 color_hit(const GeomParams& P, const uint64_t* locc2, PixCtx& c, c
     if (st.shadows) {
         f3 o = mk3(hit.pos.x + hit.normal.x * 0.01f, hit.pos.y + hit.normal.y * 0.01f, hit.pos.z + hit.normal.z * 0.01f);
         RayInt r;
-        trace_int<TRAV, OCC2_LDS>(s, locc2, o, L, st.max_steps, r);
+        trace_int<TRAV>(s.vol, occ.o2, occ.o3, o, L, st.max_steps, r);
         c.fetches += r.fetches; c.rays++;
         shadowed = r.material != 0;
     }
@@ -304,8 +225,8 @@ __device__ f3 color_hit(const GeomParams& P, const uint64_t* locc2, PixCtx& c, c
 }
 
 // colorMainRay, voxel_volume.frag:267-307
-template <int TRAV, bool OCC2_LDS>
-__device__ f3 color_main_ray(const GeomParams& P, const uint64_t* locc2, PixCtx& c, const RayHit& hit)
+template <int TRAV>
+__device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit)
 {
     const DevScene& s = P.sc;
     const vrt_settings& st = P.st;
@@ -320,18 +241,18 @@ __device__ f3 color_main_ray(const GeomParams& P, const uint64_t* locc2, PixCtx&
             f3 rdir = mk3(last.dir.x - k * last.normal.x, last.dir.y - k * last.normal.y, last.dir.z - k * last.normal.z);
             f3 o = mk3(last.pos.x + last.normal.x * 0.01f, last.pos.y + last.normal.y * 0.01f, last.pos.z + last.normal.z * 0.01f);
             RayHit rh; RayInt ri;
-            trace_ray<TRAV, OCC2_LDS>(s, locc2, o, rdir, st.max_steps, rh, ri);
+            trace_ray<TRAV>(s, occ, o, rdir, st.max_steps, rh, ri);
             c.fetches += ri.fetches; c.rays++;
             bounces[i] = rh;
             last = rh;
             if (last.material == 0 || s.palette[last.material].metallic <= 0.0f) { last_idx = i; break; }
         }
         for (int i = last_idx; i >= 0; i--) {
-            f3 col = color_hit<TRAV, OCC2_LDS>(P, locc2, c, bounces[i], reflection, (uint32_t)i);
+            f3 col = color_hit<TRAV>(P, occ, c, bounces[i], reflection, (uint32_t)i);
             reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
         }
     }
-    return color_hit<TRAV, OCC2_LDS>(P, locc2, c, hit, reflection, 0);
+    return color_hit<TRAV>(P, occ, c, hit, reflection, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,28 +277,35 @@ __device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y
     return y0 < P.pc.screen_size[1];
 }
 
-__device__ __forceinline__ void stage_occ2(const GeomParams& P, uint64_t* locc2)
+// Stage the 16^3 and 64^3 occupancy summaries into LDS (16 B per lane per iteration, coalesced).
+__device__ __forceinline__ Occ stage_occ(const GeomParams& P, uint64_t* lds)
 {
-    // 16 B per lane per iteration, coalesced; the summary is <= 64 KiB by construction.
-    const uint4* src = reinterpret_cast<const uint4*>(P.sc.occ2);
-    uint4* dst = reinterpret_cast<uint4*>(locc2);
-    uint32_t n16 = P.occ2_bytes / 16;
-    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    Occ o;
+    if (!P.occ_in_lds) { o.o2 = P.sc.vol.occ2; o.o3 = P.sc.vol.occ3; return o; }
+    const uint4* src2 = reinterpret_cast<const uint4*>(P.sc.vol.occ2);
+    const uint4* src3 = reinterpret_cast<const uint4*>(P.sc.vol.occ3);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    uint32_t n2 = P.occ2_bytes / 16, n3 = P.occ3_bytes / 16;
+    for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) dst[i] = src2[i];
+    for (uint32_t i = threadIdx.x; i < n3; i += blockDim.x) dst[n2 + i] = src3[i];
     __syncthreads();
+    o.o2 = lds; o.o3 = lds + P.occ2_bytes / 8;
+    return o;
 }
 
 // ---------------------------------------------------------------------------------------------
 // K1: primary rays
 // ---------------------------------------------------------------------------------------------
 
-template <int TRAV, bool OCC2_LDS, bool FUSED>
+template <int TRAV, bool OCC_LDS, bool FUSED>
 __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t locc2[];
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     int x0, y0;
     bool live = tile_origin(P, x0, y0);          // uniform per workgroup
     if (!live) return;
-    if (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) stage_occ2(P, locc2);
+    Occ occ; occ.o2 = P.sc.vol.occ2; occ.o3 = P.sc.vol.occ3;
+    if (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) occ = stage_occ(P, lds_occ);
 
     // wave w -> 8x8 block (w&1, w>>1); lane -> (l&7, l>>3)
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -391,7 +319,7 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
     f3 start = mk3(P.pc.cam_pos[0], P.pc.cam_pos[1], P.pc.cam_pos[2]);
     f3 dir = primary_dir(P.pc, px, py);
     RayHit h; RayInt r;
-    trace_ray<TRAV, OCC2_LDS>(s, locc2, start, dir, P.st.max_steps, h, r);
+    trace_ray<TRAV>(s, occ, start, dir, P.st.max_steps, h, r);
     bool hit = h.material != 0;
 
     const vrt_frame& f = P.fr;
@@ -421,7 +349,7 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
         f3 col;
         if (hit) {
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
-            col = color_hit<TRAV, OCC2_LDS>(P, locc2, c, h, mk3(0.0f, 0.0f, 0.0f), 0);
+            col = color_hit<TRAV>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);
         } else {
             col = sky_color(s, dir);
         }
@@ -442,14 +370,15 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
 // K2: secondary rays + shading
 // ---------------------------------------------------------------------------------------------
 
-template <int TRAV, bool OCC2_LDS>
+template <int TRAV, bool OCC_LDS>
 __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t locc2[];
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     int x0, y0;
     bool live = tile_origin(P, x0, y0);
     if (!live) return;
-    if (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) stage_occ2(P, locc2);
+    Occ occ; occ.o2 = P.sc.vol.occ2; occ.o3 = P.sc.vol.occ3;
+    if (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) occ = stage_occ(P, lds_occ);
 
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int px = x0 + (wave & 1) * 8 + (lane & 7);
@@ -470,7 +399,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     f3 col;
     if (h.material != 0) {
         h.normal = hit_normal(mask, sx, sy, sz);
-        col = color_main_ray<TRAV, OCC2_LDS>(P, locc2, c, h);
+        col = color_main_ray<TRAV>(P, occ, c, h);
     } else {
         h.normal = mk3(0.0f, 0.0f, 0.0f);
         col = sky_color(s, h.dir);
@@ -489,53 +418,52 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
 // launch plumbing for K1 / K2
 // ---------------------------------------------------------------------------------------------
 
-template <int TRAV, bool OCC2_LDS>
+template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
     dim3 grid((unsigned)(p.chunk * 8)), block(256);
-    size_t lds = (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes : 0;
-    if (p.fused_shade) hipLaunchKernelGGL((k_primary<TRAV, OCC2_LDS, true>), grid, block, lds, s, p);
-    else               hipLaunchKernelGGL((k_primary<TRAV, OCC2_LDS, false>), grid, block, lds, s, p);
+    size_t lds = (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes + p.occ3_bytes : 0;
+    if (p.fused_shade) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, true>), grid, block, lds, s, p);
+    else               hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, false>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
-template <int TRAV, bool OCC2_LDS>
+template <int TRAV, bool OCC_LDS>
 static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 {
     dim3 grid((unsigned)(p.chunk * 8)), block(256);
-    size_t lds = (OCC2_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes : 0;
-    hipLaunchKernelGGL((k_shade<TRAV, OCC2_LDS>), grid, block, lds, s, p);
+    size_t lds = (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes + p.occ3_bytes : 0;
+    hipLaunchKernelGGL((k_shade<TRAV, OCC_LDS>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
 static int effective_traversal(int t)
 {
-    if (t == VRT_TRAVERSAL_DENSE) return VRT_TRAVERSAL_DENSE;
-    return VRT_TRAVERSAL_BITMASK;   // AUTO / BITMASK / JUMP
+    if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK) return t;
+    return VRT_TRAVERSAL_JUMP;      // AUTO / JUMP
 }
 
 hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal);
     if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
-    if (p.occ2_in_lds) return launch_primary_t<VRT_TRAVERSAL_BITMASK, true>(p, s);
-    return launch_primary_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
+    if (t == VRT_TRAVERSAL_BITMASK) return p.occ_in_lds ? launch_primary_t<VRT_TRAVERSAL_BITMASK, true>(p, s) : launch_primary_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
+    return p.occ_in_lds ? launch_primary_t<VRT_TRAVERSAL_JUMP, true>(p, s) : launch_primary_t<VRT_TRAVERSAL_JUMP, false>(p, s);
 }
 
 hipError_t launch_shade(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
-    if (p.occ2_in_lds) return launch_shade_t<VRT_TRAVERSAL_BITMASK, true>(p, s);
-    return launch_shade_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
+    if (t == VRT_TRAVERSAL_BITMASK) return p.occ_in_lds ? launch_shade_t<VRT_TRAVERSAL_BITMASK, true>(p, s) : launch_shade_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
+    return p.occ_in_lds ? launch_shade_t<VRT_TRAVERSAL_JUMP, true>(p, s) : launch_shade_t<VRT_TRAVERSAL_JUMP, false>(p, s);
 }
 
-const char* primary_kernel_name(int traversal, int fused, int occ2_lds)
+const char* primary_kernel_name(int traversal, int fused, int occ_lds)
 {
     int t = effective_traversal(traversal);
-    if (t == VRT_TRAVERSAL_DENSE) return fused ? "k_primary<dense,fused>" : "k_primary<dense>";
-    if (occ2_lds) return fused ? "k_primary<bitmask,lds,fused>" : "k_primary<bitmask,lds>";
-    return fused ? "k_primary<bitmask,l2,fused>" : "k_primary<bitmask,l2>";
+    (void)fused; (void)occ_lds;
+    return t == VRT_TRAVERSAL_DENSE ? "k_primary<dense>" : (t == VRT_TRAVERSAL_BITMASK ? "k_primary<bitmask>" : "k_primary<jump>");
 }
 
 // ---------------------------------------------------------------------------------------------

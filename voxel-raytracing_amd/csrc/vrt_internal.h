@@ -6,23 +6,17 @@
 #include <stdint.h>
 
 #include "../../include/vrt.h"
+#include "vrt_traverse.h"
 
 namespace vrt {
 
 // Device view of a scene.  Layout in HBM (all hipMalloc'd, read-only during rendering):
-//   vox   W*H*D bytes, index x + y*W + z*W*H   (the reference's Texture3D upload order)
-//   occ1  one u64 per 4^3 voxels  : bit (x&3) | (y&3)<<2 | (z&3)<<4 set <=> voxel != 0      [n1x*n1y*n1z]
-//   occ2  one u64 per 16^3 voxels : bit over the 4x4x4 occ1 words, set <=> word != 0        [n2x*n2y*n2z]
-//   occ3  one u64 per 64^3 voxels : same over occ2                                           [n3x*n3y*n3z]
+//   vol.vox   W*H*D bytes, index x + y*W + z*W*H   (the reference's Texture3D upload order)
+//   vol.occ1  one u64 per 4^3 voxels  : bit (x&3) | (y&3)<<2 | (z&3)<<4 set <=> voxel != 0      [n1x*n1y*n1z]
+//   vol.occ2  one u64 per 16^3 voxels : bit over the 4x4x4 occ1 words, set <=> word != 0        [n2x*n2y*n2z]
+//   vol.occ3  one u64 per 64^3 voxels : same over occ2                                           [n3x*n3y*n3z]
 struct DevScene {
-    const uint8_t*  vox;
-    const uint64_t* occ1;
-    const uint64_t* occ2;
-    const uint64_t* occ3;
-    int32_t W, H, D;
-    int32_t n1x, n1y, n1z;
-    int32_t n2x, n2y, n2z;
-    int32_t n3x, n3y, n3z;
+    VolumeView vol;
     const vrt_material* palette;
     const float*   sky;   uint32_t sky_w, sky_h;
     const uint8_t* noise; uint32_t noise_w, noise_h;
@@ -43,8 +37,8 @@ struct GeomParams {
     int32_t    tiles_x, tiles_y_local, total_tiles, chunk;  // chunk = tiles per XCD slot
     uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)
     int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled)
-    int32_t    occ2_in_lds;    // 1: stage occ2 into LDS, 0: read it through L2
-    uint32_t   occ2_bytes;
+    int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
+    uint32_t   occ2_bytes, occ3_bytes;   // both multiples of 16
 };
 
 struct DenoiseParams {

@@ -1,0 +1,370 @@
+// vrt_traverse.h -- the grid march of voxel_volume.frag:109-174 (boxIntersection + traceRayInt) in three
+// traversal strategies that produce the SAME RayInt (hit cell, mask, sideDist, material) bit for bit:
+//
+//   DENSE    one R8 fetch per DDA iteration (the literal shader loop)
+//   BITMASK  same iterations; the solid test reads the 4^3 occupancy word cached in registers and the
+//            16^3 summary (LDS) before touching global memory; the R8 id is fetched once, at the hit
+//   JUMP     BITMASK inside occupied 4^3 cells; across EMPTY pyramid cells (4^3 / 16^3 / 64^3) one iteration
+//            replaces all the DDA iterations up to the cell's exit -- exactly (see "exact jumps" below)
+//
+// Compiled for the device by vrt_device.hip and for the host by tests/native/traverse_host.cpp (unit tests
+// of this very code against the oracle on millions of rays; the shipped library has no host render path).
+//
+// ---- exact jumps -------------------------------------------------------------------------------------
+// The shader advances sideDist by repeated fp32 addition (frag:167), so after k steps along an axis
+// sideDist = s (+) d (+) d ... (k roundings), which is not s + k*d.  Within one binade of s, however,
+// RN(s + d) = s + Q*ulp(s) for a constant integer Q (d rounded to the ulp of s; a half-ulp tie rounds to
+// even and, once the mantissa is even, keeps it even), and the bit pattern of a positive float is monotone
+// in its value.  Hence, on the bit patterns, k additions are ONE integer multiply-add, S(j) = bits + j*Q,
+// valid until the mantissa would overflow into the next binade.  The DDA's interleaving of the three
+// axes is a merge of three such arithmetic sequences by value, ties stepping together (frag:164), so the
+// state after any number of iterations is computable in closed form:
+//   n_a  = steps axis a may take before leaving the empty cell (or the binade), T_a = S_a(n_a - 1)
+//   T*   = min T_a: the sideDist value at which the last iteration of the jump happens
+//   c_a  = n_a for the axes with T_a == T*, else #{j : S_a(j) <= T*} = floor((T* - bits_a)/Q_a) + 1
+//   mask = axes whose last step was taken exactly at T*
+// The final addition of every axis that reaches T* is performed in fp32, so binade crossings are literal.
+// The iteration budget (MAX_RAY_STEPS) is tracked as bounds: every iteration steps 1..3 axes, so
+// max_a(steps_a) <= iterations <= sum_a(steps_a); a hit whose bounds straddle the budget (only possible
+// for rays with exact ties that run within a few steps of the budget) is re-traced literally.
+#pragma once
+
+#include "vrt_spec.h"
+
+#ifndef VRT_TRAVERSAL_DENSE
+#define VRT_TRAVERSAL_DENSE 1
+#define VRT_TRAVERSAL_BITMASK 2
+#define VRT_TRAVERSAL_JUMP 3
+#endif
+
+namespace vrt {
+
+// Read-only view of a scene's voxel data (device pointers on the device, host pointers in the tests).
+struct VolumeView {
+    const uint8_t*  vox;     // W*H*D, x + y*W + z*W*H
+    const uint64_t* occ1;    // per 4^3 voxels, bit (x&3)|(y&3)<<2|(z&3)<<4
+    const uint64_t* occ2;    // per 16^3
+    const uint64_t* occ3;    // per 64^3
+    int32_t W, H, D;
+    int32_t n1x, n1y, n1z;
+    int32_t n2x, n2y, n2z;
+    int32_t n3x, n3y, n3z;
+};
+
+struct RayInt {            // RayHitInternal, voxel_volume.frag:33-41
+    f3 pos, side, delta;
+    int sx, sy, sz;        // rayStep
+    int mx, my, mz;        // mapPos at loop exit
+    uint32_t material;
+    uint32_t mask;         // bit0..2
+    uint32_t fetches;      // DENSE/BITMASK: iterations that sampled a voxel (frag:157); JUMP: upper bound
+};
+
+struct TraceStats {        // host-side instrumentation (tests); a no-op type is used on the device
+    uint32_t literal = 0, jumps1 = 0, jumps2 = 0, jumps3 = 0, retrace = 0, lookups = 0;
+};
+struct NoStats {};
+VRT_HD void st_literal(TraceStats& s) { s.literal++; }
+VRT_HD void st_jump(TraceStats& s, int lvl) { if (lvl == 1) s.jumps1++; else if (lvl == 2) s.jumps2++; else s.jumps3++; }
+VRT_HD void st_retrace(TraceStats& s) { s.retrace++; }
+VRT_HD void st_lookup(TraceStats& s) { s.lookups++; }
+VRT_HD void st_literal(NoStats&) {}
+VRT_HD void st_jump(NoStats&, int) {}
+VRT_HD void st_retrace(NoStats&) {}
+VRT_HD void st_lookup(NoStats&) {}
+
+VRT_HD uint32_t f2u(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    union { float f; uint32_t u; } c; c.f = f; return c.u;
+#endif
+}
+VRT_HD float u2f(uint32_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    union { float f; uint32_t u; } c; c.u = u; return c.f;
+#endif
+}
+VRT_HD float rcp_approx(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// ---- occupancy lookups ------------------------------------------------------------------------------
+
+VRT_HD uint32_t cell_bit(int x, int y, int z) { return (uint32_t)(x & 3) | ((uint32_t)(y & 3) << 2) | ((uint32_t)(z & 3) << 4); }
+
+// occ1 word of 4^3 cell (cx,cy,cz); the 16^3 summary is consulted first so empty space costs no global access.
+VRT_HD uint64_t fetch_cell(const VolumeView& v, const uint64_t* o2, int cx, int cy, int cz)
+{
+    uint64_t w2 = o2[(cx >> 2) + ((cy >> 2) + (cz >> 2) * v.n2y) * v.n2x];
+    if (!((w2 >> cell_bit(cx, cy, cz)) & 1ull)) return 0ull;
+    return v.occ1[cx + (cy + cz * v.n1y) * v.n1x];
+}
+
+// Emptiness level of the pyramid at voxel (mx,my,mz): 3 = its 64^3 cell is empty, 2 = its 16^3 cell, 1 = its
+// 4^3 cell, 0 = the 4^3 cell holds voxels (word = its occ1 bits).
+VRT_HD int lookup_level(const VolumeView& v, const uint64_t* o2, const uint64_t* o3, int mx, int my, int mz, uint64_t& word)
+{
+    int cx = mx >> 2, cy = my >> 2, cz = mz >> 2;
+    int qx = cx >> 2, qy = cy >> 2, qz = cz >> 2;
+    uint64_t w3 = o3[(qx >> 2) + ((qy >> 2) + (qz >> 2) * v.n3y) * v.n3x];
+    word = 0ull;
+    if (w3 == 0ull) return 3;
+    if (!((w3 >> cell_bit(qx, qy, qz)) & 1ull)) return 2;
+    uint64_t w2 = o2[qx + (qy + qz * v.n2y) * v.n2x];
+    if (!((w2 >> cell_bit(cx, cy, cz)) & 1ull)) return 1;
+    word = v.occ1[cx + (cy + cz * v.n1y) * v.n1x];
+    return 0;
+}
+
+// ---- boxIntersection + DDA setup (frag:109-144) -------------------------------------------------------
+
+struct DdaState {
+    f3 p;                     // boxIntersection() result
+    int mx, my, mz;           // mapPos
+    float sdx, sdy, sdz;      // sideDist
+    float dx, dy, dz;         // deltaDist
+    int sx, sy, sz;           // rayStep
+    uint32_t mask;            // rule A initial mask
+};
+
+VRT_HD void dda_setup(const VolumeView& v, f3 start, f3 dir, DdaState& s)
+{
+    float ivx = 1.0f / dir.x, ivy = 1.0f / dir.y, ivz = 1.0f / dir.z;
+    float t1x = (-start.x) * ivx, t2x = ((float)v.W - start.x) * ivx;
+    float t1y = (-start.y) * ivy, t2y = ((float)v.H - start.y) * ivy;
+    float t1z = (-start.z) * ivz, t2z = ((float)v.D - start.z) * ivz;
+    float tnx = fminf(t1x, t2x), tny = fminf(t1y, t2y), tnz = fminf(t1z, t2z);
+    float txx = fmaxf(t1x, t2x), txy = fmaxf(t1y, t2y), txz = fmaxf(t1z, t2z);
+    float tmin = fmaxf(tnx, fmaxf(tny, tnz));
+    float tmax = fminf(txx, fminf(txy, txz));
+    s.p = start;
+    s.mask = 0;
+    if (tmin >= 0.0f && tmax >= tmin) {
+        float t = tmin + 0.1f;
+        s.p = mk3(start.x + t * dir.x, start.y + t * dir.y, start.z + t * dir.z);
+        s.mask = (uint32_t)(tnx == tmin) | ((uint32_t)(tny == tmin) << 1) | ((uint32_t)(tnz == tmin) << 2);
+    }
+    s.mx = (int)floorf(s.p.x); s.my = (int)floorf(s.p.y); s.mz = (int)floorf(s.p.z);
+    s.dx = fabsf(ivx); s.dy = fabsf(ivy); s.dz = fabsf(ivz);
+    float gx = fsign(dir.x), gy = fsign(dir.y), gz = fsign(dir.z);
+    s.sx = (int)gx; s.sy = (int)gy; s.sz = (int)gz;
+    s.sdx = ((gx * ((float)s.mx - s.p.x) + gx * 0.5f) + 0.5f) * s.dx;
+    s.sdy = ((gy * ((float)s.my - s.p.y) + gy * 0.5f) + 0.5f) * s.dy;
+    s.sdz = ((gz * ((float)s.mz - s.p.z) + gz * 0.5f) + 0.5f) * s.dz;
+}
+
+VRT_HD bool oob(const VolumeView& v, int mx, int my, int mz)
+{
+    return (uint32_t)mx >= (uint32_t)v.W || (uint32_t)my >= (uint32_t)v.H || (uint32_t)mz >= (uint32_t)v.D;
+}
+
+VRT_HD uint32_t voxel_at(const VolumeView& v, int mx, int my, int mz)
+{
+    return v.vox[(size_t)mx + ((size_t)my + (size_t)mz * (size_t)v.H) * (size_t)v.W];
+}
+
+// one literal DDA iteration's advance (frag:164-170)
+#define VRT_DDA_STEP(S, MASK)                                                         \
+    do {                                                                              \
+        bool m0_ = (S).sdx <= fminf((S).sdy, (S).sdz);                                \
+        bool m1_ = (S).sdy <= fminf((S).sdz, (S).sdx);                                \
+        bool m2_ = (S).sdz <= fminf((S).sdx, (S).sdy);                                \
+        (MASK) = (uint32_t)m0_ | ((uint32_t)m1_ << 1) | ((uint32_t)m2_ << 2);         \
+        if (m0_) { (S).sdx = (S).sdx + (S).dx; (S).mx += (S).sx; }                    \
+        if (m1_) { (S).sdy = (S).sdy + (S).dy; (S).my += (S).sy; }                    \
+        if (m2_) { (S).sdz = (S).sdz + (S).dz; (S).mz += (S).sz; }                    \
+    } while (0)
+
+VRT_HD void finish(const DdaState& s, uint32_t material, uint32_t mask, uint32_t fetches, RayInt& r)
+{
+    r.pos = s.p; r.side = mk3(s.sdx, s.sdy, s.sdz); r.delta = mk3(s.dx, s.dy, s.dz);
+    r.sx = s.sx; r.sy = s.sy; r.sz = s.sz; r.mx = s.mx; r.my = s.my; r.mz = s.mz;
+    r.material = material; r.mask = mask; r.fetches = fetches;
+}
+
+// ---- literal traversals ---------------------------------------------------------------------------------
+
+template <int TRAV>
+VRT_HD void trace_literal(const VolumeView& v, const uint64_t* o2, f3 start, f3 dir, uint32_t maxSteps, RayInt& r)
+{
+    DdaState s;
+    dda_setup(v, start, dir, s);
+    uint32_t mask = s.mask, material = 0, fetches = 0;
+    uint32_t ckey = 0xFFFFFFFFu;
+    uint64_t word = 0;
+    uint32_t i = 0;
+    for (; i < maxSteps; i++) {
+        if (oob(v, s.mx, s.my, s.mz)) break;
+        if (TRAV == VRT_TRAVERSAL_DENSE) {
+            material = voxel_at(v, s.mx, s.my, s.mz);
+            if (material != 0) { fetches = i + 1; break; }
+        } else {
+            uint32_t key = (uint32_t)(s.mx >> 2) | ((uint32_t)(s.my >> 2) << 10) | ((uint32_t)(s.mz >> 2) << 20);
+            if (key != ckey) { ckey = key; word = fetch_cell(v, o2, s.mx >> 2, s.my >> 2, s.mz >> 2); }
+            if ((word >> cell_bit(s.mx, s.my, s.mz)) & 1ull) {
+                material = voxel_at(v, s.mx, s.my, s.mz);
+                fetches = i + 1;
+                break;
+            }
+        }
+        VRT_DDA_STEP(s, mask);
+    }
+    if (material == 0) fetches = i;
+    finish(s, material, mask, fetches, r);
+}
+
+// ---- exact jumps ----------------------------------------------------------------------------------------
+
+// Increment of the bit pattern per addition of d while the sum stays in the binade of `bits`, and how many
+// further additions are guaranteed to stay there (conservative).  false: no closed form here (zero/denormal/
+// inf sideDist, d not below the binade of s, or a half-ulp tie on an odd mantissa) -> step that axis literally.
+VRT_HD bool axis_increment(uint32_t bits, float d, uint32_t& Q, uint32_t& jmax)
+{
+    uint32_t db = f2u(d);
+    uint32_t E = bits >> 23, Ed = db >> 23;
+    int shift = (int)E - (int)Ed;
+    if (E == 0u || E >= 255u || shift < 1 || shift > 20) return false;
+    uint32_t Md = (db & 0x7FFFFFu) | 0x800000u;
+    uint32_t q = Md >> shift;
+    uint32_t rem = Md & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half) q += 1u;
+    else if (rem == half) { if (bits & 1u) return false; q += (q & 1u); }
+    uint32_t room = 0xFFFFFFu - ((bits & 0x7FFFFFu) | 0x800000u);       // mantissa head-room in this binade
+    uint32_t je = (uint32_t)((float)room * rcp_approx((float)q));
+    jmax = je > 0u ? je - 1u : 0u;                                       // conservative: never over-estimates
+    Q = q;
+    return true;
+}
+
+struct JumpAxis { uint32_t bits, Q, T; int n; };
+
+VRT_HD void jump_axis_prepare(float side, float d, int step, int n_region, JumpAxis& a)
+{
+    a.bits = f2u(side);
+    a.Q = 0u;
+    if (step == 0) { a.n = 0; a.T = 0xFFFFFFFFu; return; }
+    uint32_t jmax;
+    if (axis_increment(a.bits, d, a.Q, jmax)) {
+        int lim = (int)jmax + 1;
+        a.n = n_region < lim ? n_region : lim;
+    } else {
+        a.n = 1; a.Q = 0u;
+    }
+    a.T = a.bits + (uint32_t)(a.n - 1) * a.Q;
+}
+
+// Advance axis by the steps it takes up to and including time T*.  Returns the number of steps; `last` tells
+// whether its final step happened exactly at T* (it then belongs to the final iteration's mask).
+VRT_HD int jump_axis_apply(const JumpAxis& a, uint32_t Tstar, float d, float& side, bool& last)
+{
+    last = false;
+    if (a.n == 0) return 0;
+    if (a.T == Tstar) {                                   // reaches its n-th step at T*: last addition in fp32
+        side = u2f(a.T) + d;
+        last = true;
+        return a.n;
+    }
+    if (a.Q == 0u || Tstar < a.bits) return 0;
+    uint32_t num = Tstar - a.bits;
+    uint32_t c = (uint32_t)((float)num * rcp_approx((float)a.Q));
+    if (c * a.Q > num) c -= 1u;
+    else if ((c + 1u) * a.Q <= num) c += 1u;
+    last = (c * a.Q == num);
+    c += 1u;                                              // steps j = 0..c-1 have S(j) <= T*
+    side = u2f(a.bits + c * a.Q);
+    return (int)c;
+}
+
+VRT_HD int iabs(int x) { return x < 0 ? -x : x; }
+
+template <class STATS>
+VRT_HD void trace_jump(const VolumeView& v, const uint64_t* o2, const uint64_t* o3, f3 start, f3 dir,
+                       uint32_t maxSteps, RayInt& r, STATS& stats)
+{
+    DdaState s;
+    dda_setup(v, start, dir, s);
+    const int mx0 = s.mx, my0 = s.my, mz0 = s.mz;
+    uint32_t mask = s.mask, material = 0;
+    uint32_t it_up = 0;                                   // upper bound of DDA iterations done (sum of axis steps)
+    uint32_t ckey = 0xFFFFFFFFu;
+    uint64_t word = 0;
+    int lvl = 0;
+    bool hit = false;
+    for (;;) {
+        if (oob(v, s.mx, s.my, s.mz)) break;
+        uint32_t key = (uint32_t)(s.mx >> 2) | ((uint32_t)(s.my >> 2) << 10) | ((uint32_t)(s.mz >> 2) << 20);
+        if (key != ckey) { ckey = key; lvl = lookup_level(v, o2, o3, s.mx, s.my, s.mz, word); st_lookup(stats); }
+        if (lvl == 0) {
+            if ((word >> cell_bit(s.mx, s.my, s.mz)) & 1ull) { hit = true; break; }
+            VRT_DDA_STEP(s, mask);
+            it_up += (mask & 1u) + ((mask >> 1) & 1u) + ((mask >> 2) & 1u);
+            st_literal(stats);
+        } else {
+            // empty aligned cell of edge sz around mapPos, clipped to the volume
+            int sh = 2 * lvl, sz = 1 << sh;
+            int lox = (s.mx >> sh) << sh, loy = (s.my >> sh) << sh, loz = (s.mz >> sh) << sh;
+            int hix = lox + sz < v.W ? lox + sz : v.W;
+            int hiy = loy + sz < v.H ? loy + sz : v.H;
+            int hiz = loz + sz < v.D ? loz + sz : v.D;
+            JumpAxis ax, ay, az;
+            jump_axis_prepare(s.sdx, s.dx, s.sx, s.sx > 0 ? hix - s.mx : s.mx - lox + 1, ax);
+            jump_axis_prepare(s.sdy, s.dy, s.sy, s.sy > 0 ? hiy - s.my : s.my - loy + 1, ay);
+            jump_axis_prepare(s.sdz, s.dz, s.sz, s.sz > 0 ? hiz - s.mz : s.mz - loz + 1, az);
+            uint32_t Tstar = ax.T < ay.T ? ax.T : ay.T;
+            Tstar = Tstar < az.T ? Tstar : az.T;
+            if (Tstar == 0xFFFFFFFFu) break;              // direction (0,0,0): the literal loop spins to the budget -> miss
+            bool l0, l1, l2;
+            int c0 = jump_axis_apply(ax, Tstar, s.dx, s.sdx, l0);
+            int c1 = jump_axis_apply(ay, Tstar, s.dy, s.sdy, l1);
+            int c2 = jump_axis_apply(az, Tstar, s.dz, s.sdz, l2);
+            s.mx += c0 * s.sx; s.my += c1 * s.sy; s.mz += c2 * s.sz;
+            mask = (uint32_t)l0 | ((uint32_t)l1 << 1) | ((uint32_t)l2 << 2);
+            it_up += (uint32_t)(c0 + c1 + c2);
+            st_jump(stats, lvl);
+            // every iteration steps each axis at most once: once one axis alone has taken maxSteps steps the
+            // literal loop is certainly exhausted
+            int klo = iabs(s.mx - mx0); int k1 = iabs(s.my - my0); int k2 = iabs(s.mz - mz0);
+            klo = klo > k1 ? klo : k1; klo = klo > k2 ? klo : k2;
+            if ((uint32_t)klo >= maxSteps) break;
+        }
+    }
+    if (hit) {
+        int klo = iabs(s.mx - mx0); int k1 = iabs(s.my - my0); int k2 = iabs(s.mz - mz0);
+        klo = klo > k1 ? klo : k1; klo = klo > k2 ? klo : k2;
+        if (it_up < maxSteps) {
+            material = voxel_at(v, s.mx, s.my, s.mz);     // the literal loop reaches this fetch within its budget
+        } else if ((uint32_t)klo >= maxSteps) {
+            hit = false;                                  // certainly exhausted before reaching this voxel
+        } else {
+            st_retrace(stats);                            // ties make the count ambiguous: decide literally
+            trace_literal<VRT_TRAVERSAL_BITMASK>(v, o2, start, dir, maxSteps, r);
+            return;
+        }
+    }
+    finish(s, material, mask, hit ? it_up + 1u : it_up, r);
+}
+
+// Dispatcher used by the kernels.
+template <int TRAV>
+VRT_HD void trace_int(const VolumeView& v, const uint64_t* o2, const uint64_t* o3, f3 start, f3 dir,
+                      uint32_t maxSteps, RayInt& r)
+{
+    if (TRAV == VRT_TRAVERSAL_JUMP) {
+        NoStats ns;
+        trace_jump(v, o2, o3, start, dir, maxSteps, r, ns);
+    } else {
+        trace_literal<TRAV>(v, o2, start, dir, maxSteps, r);
+    }
+}
+
+} // namespace vrt
