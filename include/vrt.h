@@ -57,15 +57,16 @@ typedef struct vrt_push {
     float    camera_jitter[2];
 } vrt_push;
 
-/* Traversal strategies.  All three produce bit-identical hit records, G-buffers and step budgets
- * (the DDA state is advanced with the same fp32 additions, voxel_volume.frag:164-170); they differ
- * only in how much memory work / ALU work is skipped. */
-#define VRT_TRAVERSAL_AUTO    0   /* best available (currently JUMP) */
-#define VRT_TRAVERSAL_DENSE   1   /* one R8 fetch per DDA step, literally voxel_volume.frag:157 */
-#define VRT_TRAVERSAL_BITMASK 2   /* 4^3 occupancy words (L2) + 16^3 summary staged in LDS; ALU-only stepping */
-#define VRT_TRAVERSAL_JUMP    3   /* BITMASK + exact multi-step jumps across empty pyramid cells */
+/* Traversal strategies.  All of them produce bit-identical hit records and G-buffers (the DDA state is
+ * advanced with the same fp32 additions as voxel_volume.frag:164-170); they differ only in how much memory
+ * work is skipped.  steps_* planes are exact for DENSE / BITMASK / DF and upper bounds for JUMP. */
+#define VRT_TRAVERSAL_AUTO    0   /* fastest available (currently DF) */
+#define VRT_TRAVERSAL_DENSE   1   /* one R8 fetch per DDA iteration (voxel_volume.frag:157), fetched 4 iterations ahead */
+#define VRT_TRAVERSAL_BITMASK 2   /* solid test on 4^3 occupancy words (L2) + 16^3 / 64^3 summaries staged in LDS */
+#define VRT_TRAVERSAL_JUMP    3   /* BITMASK + exact closed-form jumps across empty pyramid cells */
+#define VRT_TRAVERSAL_DF      4   /* distance-field clearance agreed per wave by ballot; ALU-only runs between fetches */
 
-#define VRT_FLAG_DEBUG_PLANES 1u  /* reserved */
+#define VRT_FLAG_DEBUG_PLANES 1u  /* steps_total / rays_total receive traversal diagnostics instead (development aid) */
 
 /* VolumeParameters (parameters.hpp:5-9) + Light (voxel_scene.hpp:10-15) as GeometryStage::record fills
  * them each frame (geometry_stage.cpp:135-145), plus the shader's compile-time constants

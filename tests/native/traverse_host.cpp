@@ -13,6 +13,7 @@ struct HostVolume {
     VolumeView v;
     std::vector<uint8_t> vox;
     std::vector<uint64_t> o1, o2, o3;
+    std::vector<uint8_t> df;
 };
 
 static void build_up(const std::vector<uint64_t>& lo, int lx, int ly, int lz, std::vector<uint64_t>& hi, int hx, int hy, int hz)
@@ -40,6 +41,33 @@ void* th_create(const uint8_t* vox, int W, int H, int D)
             h->o1[(size_t)(x >> 2) + ((size_t)(y >> 2) + (size_t)(z >> 2) * v.n1y) * v.n1x] |= 1ull << cell_bit(x, y, z);
     build_up(h->o1, v.n1x, v.n1y, v.n1z, h->o2, v.n2x, v.n2y, v.n2z);
     build_up(h->o2, v.n2x, v.n2y, v.n2z, h->o3, v.n3x, v.n3y, v.n3z);
+    // distance field: three 1-D min-max passes (same definition as k_df_pass, written independently)
+    {
+        const int CAP = 63;
+        std::vector<uint8_t> a((size_t)W * H * D), b((size_t)W * H * D);
+        for (size_t i = 0; i < a.size(); i++) a[i] = h->vox[i] ? 0 : CAP + 1;
+        for (int axis = 0; axis < 3; axis++) {
+            for (int z = 0; z < D; z++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+                size_t i = (size_t)x + ((size_t)y + (size_t)z * H) * W;
+                int pos = axis == 0 ? x : (axis == 1 ? y : z), dim = axis == 0 ? W : (axis == 1 ? H : D);
+                size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)W : (size_t)W * H);
+                int best = a[i];
+                for (int t = 1; t < best; t++) {
+                    int lo = pos - t < 0 ? CAP + 1 : a[i - t * stride], hi = pos + t >= dim ? CAP + 1 : a[i + t * stride];
+                    int m = lo < hi ? lo : hi; if (m < t) m = t;
+                    if (m < best) best = m;
+                }
+                b[i] = (uint8_t)best;
+            }
+            a.swap(b);
+        }
+        h->df.assign((size_t)v.n1x * v.n1y * v.n1z * 64, 0);
+        for (int z = 0; z < D; z++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+            size_t i = (size_t)x + ((size_t)y + (size_t)z * H) * W;
+            h->df[df_index(v, x, y, z)] = a[i] > CAP ? CAP : a[i];
+        }
+    }
+    v.df = h->df.data();
     v.vox = h->vox.data(); v.occ1 = h->o1.data(); v.occ2 = h->o2.data(); v.occ3 = h->o3.data();
     return h;
 }
@@ -62,6 +90,10 @@ void th_trace(void* p, int trav, int n, const float* starts, const float* dirs, 
             total.retrace += st.retrace; total.lookups += st.lookups;
         } else if (trav == VRT_TRAVERSAL_BITMASK) {
             trace_literal<VRT_TRAVERSAL_BITMASK>(h->v, h->v.occ2, s, d, maxSteps, r);
+        } else if (trav == VRT_TRAVERSAL_DF) {
+            TraceStats st;
+            trace_df(h->v, s, d, maxSteps, r, st);
+            total.jumps1 += st.jumps1; total.jumps2 += st.jumps2; total.lookups += st.lookups;
         } else {
             trace_literal<VRT_TRAVERSAL_DENSE>(h->v, h->v.occ2, s, d, maxSteps, r);
         }

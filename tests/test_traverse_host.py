@@ -78,7 +78,7 @@ def test_strategies_match_oracle_random_rays(th, oracle, seed, dims, fill):
     starts, dirs = _rays(rng, 6000, dims)
     for max_steps in (512, 64, 37):
         exp = oracle_trace(oracle, osn, starts, dirs, max_steps)
-        for trav, name in ((1, "DENSE"), (2, "BITMASK"), (3, "JUMP")):
+        for trav, name in ((1, "DENSE"), (2, "BITMASK"), (4, "DF"), (3, "JUMP")):
             got, stats = trace(th, h, trav, starts, dirs, max_steps)
             cols = slice(0, 12) if trav != 3 else slice(0, 11)          # JUMP's fetch count is an upper bound
             bad = np.flatnonzero((got[:, cols] != exp[:, cols]).any(axis=1))

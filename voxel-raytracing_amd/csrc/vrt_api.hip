@@ -49,6 +49,7 @@ struct vrt_scene {
     DevScene d{};
     uint8_t* vox = nullptr;
     uint64_t *occ1 = nullptr, *occ2 = nullptr, *occ3 = nullptr;
+    uint8_t* df = nullptr;
     vrt_material* palette = nullptr;
     float* sky = nullptr;
     uint8_t* noise = nullptr;
@@ -180,6 +181,7 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->occ1) hipFree(s->occ1);
     if (s->occ2) hipFree(s->occ2);
     if (s->occ3) hipFree(s->occ3);
+    if (s->df) hipFree(s->df);
     if (s->palette) hipFree(s->palette);
     if (s->sky) hipFree(s->sky);
     if (s->noise) hipFree(s->noise);
@@ -231,6 +233,7 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     size_t n1 = (size_t)d.n1x * d.n1y * d.n1z, n2 = (size_t)d.n2x * d.n2y * d.n2z, n3 = (size_t)d.n3x * d.n3y * d.n3z;
     size_t n2pad = (n2 + 1) & ~(size_t)1;          // 16-byte multiples for the uint4 LDS staging loop
     size_t n3pad = (n3 + 1) & ~(size_t)1;
+    size_t ndf = n1 * 64;                          // distance field, bricked: 64 B per 4^3 cell (>= nvox)
     int rc = VRT_OK;
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
     SCHK(hipMalloc((void**)&s->vox, nvox));
@@ -238,14 +241,23 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     SCHK(hipMalloc((void**)&s->occ2, n2pad * 8));
     SCHK(hipMalloc((void**)&s->occ3, n3pad * 8));
     SCHK(hipMalloc((void**)&s->palette, 256 * sizeof(vrt_material)));
+    SCHK(hipMalloc((void**)&s->df, ndf));
+    SCHK(hipMemsetAsync(s->df, 0, ndf, c->stream));
     SCHK(hipMemsetAsync(s->occ2, 0, n2pad * 8, c->stream));
     SCHK(hipMemsetAsync(s->occ3, 0, n3pad * 8, c->stream));
     SCHK(hipMemcpyAsync(s->vox, voxels, nvox, hipMemcpyHostToDevice, c->stream));
     SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_build_pyramid(s->vox, d.W, d.H, d.D, s->occ1, s->occ2, s->occ3, c->stream));
-    SCHK(hipStreamSynchronize(c->stream));
+    {
+        uint8_t* tmp = nullptr;                                   // ping-pong buffer of the 3-pass distance transform
+        SCHK(hipMalloc((void**)&tmp, nvox));
+        hipError_t df_launch = launch_build_df(s->vox, d.W, d.H, d.D, s->df, tmp, c->stream);
+        hipError_t df_sync = hipStreamSynchronize(c->stream);
+        hipFree(tmp);
+        SCHK(df_launch); SCHK(df_sync);
+    }
 #undef SCHK
-    d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; s->d.palette = s->palette;
+    d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.df = s->df; s->d.palette = s->palette;
     s->occ2_bytes = (uint32_t)(n2pad * 8); s->occ3_bytes = (uint32_t)(n3pad * 8);
     {
         const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -396,7 +408,9 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     if (push->volume_bounds[0] != (uint32_t)s->d.vol.W || push->volume_bounds[1] != (uint32_t)s->d.vol.H || push->volume_bounds[2] != (uint32_t)s->d.vol.D)
         return fail(VRT_ERR_INVALID, "vrt_render_geometry: push.volume_bounds must equal the scene dimensions (voxel_renderer.cpp:74)");
     if (st->max_bounces > VRT_MAX_BOUNCES) return fail(VRT_ERR_INVALID, "vrt_render_geometry: max_bounces > VRT_MAX_BOUNCES");
-    if (st->traversal > VRT_TRAVERSAL_JUMP) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
+    if (st->traversal > VRT_TRAVERSAL_DF) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
+    if (st->traversal == VRT_TRAVERSAL_DENSE && (uint64_t)s->d.vol.W * (uint64_t)s->d.vol.H * (uint64_t)s->d.vol.D > 0xFFFFFFFFull)
+        return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: VRT_TRAVERSAL_DENSE indexes voxels in 32 bits (volumes below 4 GiB)");
     HIPCHK(hipSetDevice(c->device));
 
     GeomParams p;

@@ -83,6 +83,52 @@ hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_
 }
 
 // ---------------------------------------------------------------------------------------------
+// distance field (scene build): Chebyshev distance to the nearest solid voxel,
+// d(p) = min_q max(|dx|,|dy|,|dz|) = min_dz max(|dz|, min_dy max(|dy|, min_dx |dx|)): three 1-D min-max passes.
+// ---------------------------------------------------------------------------------------------
+
+#define VRT_DF_CAP 63
+
+// src == nullptr: first pass, the field is (vox != 0 ? 0 : INF).  Outside the volume counts as empty.
+__global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox, const uint8_t* __restrict__ src,
+                                                 uint8_t* __restrict__ dst, int W, int H, int D, int axis, int bricked)
+{
+    size_t n = (size_t)W * H * D;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x = (int)(i % (size_t)W), y = (int)((i / (size_t)W) % (size_t)H), z = (int)(i / ((size_t)W * H));
+    int pos = axis == 0 ? x : (axis == 1 ? y : z);
+    int dim = axis == 0 ? W : (axis == 1 ? H : D);
+    size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)W : (size_t)W * H);
+    int best = src ? (int)src[i] : (vox[i] != 0 ? 0 : VRT_DF_CAP + 1);
+    for (int t = 1; t < best; t++) {
+        int lo = pos - t < 0 ? VRT_DF_CAP + 1 : (src ? (int)src[i - (size_t)t * stride] : (vox[i - (size_t)t * stride] != 0 ? 0 : VRT_DF_CAP + 1));
+        int hi = pos + t >= dim ? VRT_DF_CAP + 1 : (src ? (int)src[i + (size_t)t * stride] : (vox[i + (size_t)t * stride] != 0 ? 0 : VRT_DF_CAP + 1));
+        int m = lo < hi ? lo : hi;
+        m = m > t ? m : t;
+        best = best < m ? best : m;
+    }
+    size_t o = i;
+    if (bricked) {                                           // final pass: 4x4x4 bricks of 64 B (vrt_traverse.h df_index)
+        size_t n1x = (size_t)(W + 3) / 4, n1y = (size_t)(H + 3) / 4;
+        o = ((size_t)(x >> 2) + ((size_t)(y >> 2) + (size_t)(z >> 2) * n1y) * n1x) * 64u + (size_t)((x & 3) | ((y & 3) << 2) | ((z & 3) << 4));
+    }
+    dst[o] = (uint8_t)(best > VRT_DF_CAP ? VRT_DF_CAP : best);
+}
+
+hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, uint8_t* tmp, hipStream_t s)
+{
+    size_t n = (size_t)W * H * D;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    // pass values stay <= CAP + 1 = 64 until the final clamp, which every pass applies (harmless: min-max of
+    // clamped fields equals the clamped min-max)
+    hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)nullptr, df, W, H, D, 0, 0);
+    hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)df, tmp, W, H, D, 1, 0);
+    hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp, df, W, H, D, 2, 1);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // traversal
 // ---------------------------------------------------------------------------------------------
 
@@ -91,8 +137,12 @@ struct RayHit {            // RayHit, voxel_volume.frag:43-49
     f3 pos, normal, dir;
 };
 
-// occupancy summaries as seen by a workgroup: LDS copies when they fit, the L2-resident originals otherwise
-struct Occ { const uint64_t* o2; const uint64_t* o3; };
+// Occupancy summaries as seen by a workgroup: LDS copies when they fit (typed address_space(3) pointers, so
+// that the lookups compile to ds_read_b64 and not to flat loads), the L2-resident originals otherwise.
+typedef const __attribute__((address_space(3))) uint64_t* lds_u64_ptr;
+template <bool LDS> struct OccT;
+template <> struct OccT<true>  { lds_u64_ptr o2, o3; };
+template <> struct OccT<false> { const uint64_t* o2; const uint64_t* o3; };
 
 __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 {
@@ -101,7 +151,7 @@ __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 }
 
 // traceRay, voxel_volume.frag:176-196
-template <int TRAV>
+template <int TRAV, class Occ>
 __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 start, f3 dir,
                                           uint32_t maxSteps, RayHit& h, RayInt& r)
 {
@@ -171,7 +221,7 @@ __device__ __forceinline__ f3 primary_dir(const vrt_push& pc, int px, int py)
 }
 
 // calcAmbient + isShadowed + color + colorHit, voxel_volume.frag:205-264
-template <int TRAV>
+template <int TRAV, class Occ>
 __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit,
                         f3 reflection, uint32_t depth)
 {
@@ -190,7 +240,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
             f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
             RayInt r;
             // AO rays have a 64-iteration budget: too short for jumps to pay, and budget ties would force re-traces
-            trace_int<(TRAV == VRT_TRAVERSAL_JUMP ? VRT_TRAVERSAL_BITMASK : TRAV)>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);
+            trace_int<(TRAV == VRT_TRAVERSAL_JUMP ? VRT_TRAVERSAL_DF : TRAV)>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);
             c.fetches += r.fetches; c.rays++;
             if (r.material != 0) ambient += sample_frac;
         }
@@ -225,7 +275,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
 }
 
 // colorMainRay, voxel_volume.frag:267-307
-template <int TRAV>
+template <int TRAV, class Occ>
 __device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit)
 {
     const DevScene& s = P.sc;
@@ -278,10 +328,13 @@ __device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y
 }
 
 // Stage the 16^3 and 64^3 occupancy summaries into LDS (16 B per lane per iteration, coalesced).
-__device__ __forceinline__ Occ stage_occ(const GeomParams& P, uint64_t* lds)
+template <bool LDS> __device__ __forceinline__ OccT<LDS> stage_occ(const GeomParams& P, uint64_t* lds);
+template <> __device__ __forceinline__ OccT<false> stage_occ<false>(const GeomParams& P, uint64_t*)
 {
-    Occ o;
-    if (!P.occ_in_lds) { o.o2 = P.sc.vol.occ2; o.o3 = P.sc.vol.occ3; return o; }
+    OccT<false> o; o.o2 = P.sc.vol.occ2; o.o3 = P.sc.vol.occ3; return o;
+}
+template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomParams& P, uint64_t* lds)
+{
     const uint4* src2 = reinterpret_cast<const uint4*>(P.sc.vol.occ2);
     const uint4* src3 = reinterpret_cast<const uint4*>(P.sc.vol.occ3);
     uint4* dst = reinterpret_cast<uint4*>(lds);
@@ -289,7 +342,8 @@ __device__ __forceinline__ Occ stage_occ(const GeomParams& P, uint64_t* lds)
     for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) dst[i] = src2[i];
     for (uint32_t i = threadIdx.x; i < n3; i += blockDim.x) dst[n2 + i] = src3[i];
     __syncthreads();
-    o.o2 = lds; o.o3 = lds + P.occ2_bytes / 8;
+    OccT<true> o;
+    o.o2 = (lds_u64_ptr)lds; o.o3 = (lds_u64_ptr)(lds + P.occ2_bytes / 8);
     return o;
 }
 
@@ -304,8 +358,8 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
     int x0, y0;
     bool live = tile_origin(P, x0, y0);          // uniform per workgroup
     if (!live) return;
-    Occ occ; occ.o2 = P.sc.vol.occ2; occ.o3 = P.sc.vol.occ3;
-    if (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) occ = stage_occ(P, lds_occ);
+    constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
+    const OccT<kLds> occ = stage_occ<kLds>(P, lds_occ);
 
     // wave w -> 8x8 block (w&1, w>>1); lane -> (l&7, l>>3)
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -341,8 +395,8 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
     }
     if (f.hit_mask) f.hit_mask[i] = hit ? (uint8_t)r.mask : (uint8_t)0;
     if (f.steps_primary) f.steps_primary[i] = r.fetches;
-    if (f.steps_total) f.steps_total[i] = r.fetches;
-    if (f.rays_total) f.rays_total[i] = 1;
+    if (f.steps_total) f.steps_total[i] = (P.st.flags & VRT_FLAG_DEBUG_PLANES) ? r.dbg0 : r.fetches;
+    if (f.rays_total) f.rays_total[i] = (P.st.flags & VRT_FLAG_DEBUG_PLANES) ? r.dbg1 : 1u;
 
     if (FUSED) {
         // no secondary rays enabled: shade here (ambient = 1, not shadowed, reflection = 0)
@@ -377,8 +431,8 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     int x0, y0;
     bool live = tile_origin(P, x0, y0);
     if (!live) return;
-    Occ occ; occ.o2 = P.sc.vol.occ2; occ.o3 = P.sc.vol.occ3;
-    if (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) occ = stage_occ(P, lds_occ);
+    constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
+    const OccT<kLds> occ = stage_occ<kLds>(P, lds_occ);
 
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int px = x0 + (wave & 1) * 8 + (lane & 7);
@@ -422,7 +476,7 @@ template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
     dim3 grid((unsigned)(p.chunk * 8)), block(256);
-    size_t lds = (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes + p.occ3_bytes : 0;
+    size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     if (p.fused_shade) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, true>), grid, block, lds, s, p);
     else               hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, false>), grid, block, lds, s, p);
     return hipGetLastError();
@@ -432,21 +486,22 @@ template <int TRAV, bool OCC_LDS>
 static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 {
     dim3 grid((unsigned)(p.chunk * 8)), block(256);
-    size_t lds = (OCC_LDS && TRAV != VRT_TRAVERSAL_DENSE) ? p.occ2_bytes + p.occ3_bytes : 0;
+    size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     hipLaunchKernelGGL((k_shade<TRAV, OCC_LDS>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
 static int effective_traversal(int t)
 {
-    if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK) return t;
-    return VRT_TRAVERSAL_JUMP;      // AUTO / JUMP
+    if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP) return t;
+    return VRT_TRAVERSAL_DF;        // AUTO / DF
 }
 
 hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal);
     if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
+    if (t == VRT_TRAVERSAL_DF) return launch_primary_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_BITMASK) return p.occ_in_lds ? launch_primary_t<VRT_TRAVERSAL_BITMASK, true>(p, s) : launch_primary_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
     return p.occ_in_lds ? launch_primary_t<VRT_TRAVERSAL_JUMP, true>(p, s) : launch_primary_t<VRT_TRAVERSAL_JUMP, false>(p, s);
 }
@@ -455,6 +510,7 @@ hipError_t launch_shade(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
+    if (t == VRT_TRAVERSAL_DF) return launch_shade_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_BITMASK) return p.occ_in_lds ? launch_shade_t<VRT_TRAVERSAL_BITMASK, true>(p, s) : launch_shade_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
     return p.occ_in_lds ? launch_shade_t<VRT_TRAVERSAL_JUMP, true>(p, s) : launch_shade_t<VRT_TRAVERSAL_JUMP, false>(p, s);
 }
@@ -463,7 +519,7 @@ const char* primary_kernel_name(int traversal, int fused, int occ_lds)
 {
     int t = effective_traversal(traversal);
     (void)fused; (void)occ_lds;
-    return t == VRT_TRAVERSAL_DENSE ? "k_primary<dense>" : (t == VRT_TRAVERSAL_BITMASK ? "k_primary<bitmask>" : "k_primary<jump>");
+    return t == VRT_TRAVERSAL_DENSE ? "k_primary<dense>" : (t == VRT_TRAVERSAL_BITMASK ? "k_primary<bitmask>" : (t == VRT_TRAVERSAL_DF ? "k_primary<df>" : "k_primary<jump>"));
 }
 
 // ---------------------------------------------------------------------------------------------

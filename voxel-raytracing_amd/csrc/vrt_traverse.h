@@ -1,9 +1,11 @@
 // vrt_traverse.h -- the grid march of voxel_volume.frag:109-174 (boxIntersection + traceRayInt) in three
-// traversal strategies that produce the SAME RayInt (hit cell, mask, sideDist, material) bit for bit:
+// traversal strategies that all produce the SAME RayInt (hit cell, mask, sideDist, material) bit for bit:
 //
 //   DENSE    one R8 fetch per DDA iteration (the literal shader loop)
 //   BITMASK  same iterations; the solid test reads the 4^3 occupancy word cached in registers and the
 //            16^3 summary (LDS) before touching global memory; the R8 id is fetched once, at the hit
+//   DF       the wave agrees by ballot on a number of iterations no lane needs a memory test for (distance
+//            field clearance) and runs them as pure ALU stepping; one gather per run instead of per iteration
 //   JUMP     BITMASK inside occupied 4^3 cells; across EMPTY pyramid cells (4^3 / 16^3 / 64^3) one iteration
 //            replaces all the DDA iterations up to the cell's exit -- exactly (see "exact jumps" below)
 //
@@ -35,6 +37,7 @@
 #define VRT_TRAVERSAL_DENSE 1
 #define VRT_TRAVERSAL_BITMASK 2
 #define VRT_TRAVERSAL_JUMP 3
+#define VRT_TRAVERSAL_DF 4
 #endif
 
 namespace vrt {
@@ -45,6 +48,8 @@ struct VolumeView {
     const uint64_t* occ1;    // per 4^3 voxels, bit (x&3)|(y&3)<<2|(z&3)<<4
     const uint64_t* occ2;    // per 16^3
     const uint64_t* occ3;    // per 64^3
+    const uint8_t*  df;      // 64-byte bricks of 4^3 voxels (df_index): 0 = solid, else min(63, Chebyshev distance to the
+                             // nearest solid voxel)
     int32_t W, H, D;
     int32_t n1x, n1y, n1z;
     int32_t n2x, n2y, n2z;
@@ -58,6 +63,7 @@ struct RayInt {            // RayHitInternal, voxel_volume.frag:33-41
     uint32_t material;
     uint32_t mask;         // bit0..2
     uint32_t fetches;      // DENSE/BITMASK: iterations that sampled a voxel (frag:157); JUMP: upper bound
+    uint32_t dbg0, dbg1;   // traversal diagnostics (outer iterations / near-regime iterations of trace_skip)
 };
 
 struct TraceStats {        // host-side instrumentation (tests); a no-op type is used on the device
@@ -103,7 +109,8 @@ VRT_HD float rcp_approx(float x)
 VRT_HD uint32_t cell_bit(int x, int y, int z) { return (uint32_t)(x & 3) | ((uint32_t)(y & 3) << 2) | ((uint32_t)(z & 3) << 4); }
 
 // occ1 word of 4^3 cell (cx,cy,cz); the 16^3 summary is consulted first so empty space costs no global access.
-VRT_HD uint64_t fetch_cell(const VolumeView& v, const uint64_t* o2, int cx, int cy, int cz)
+template <class OP>
+VRT_HD uint64_t fetch_cell(const VolumeView& v, OP o2, int cx, int cy, int cz)
 {
     uint64_t w2 = o2[(cx >> 2) + ((cy >> 2) + (cz >> 2) * v.n2y) * v.n2x];
     if (!((w2 >> cell_bit(cx, cy, cz)) & 1ull)) return 0ull;
@@ -112,7 +119,8 @@ VRT_HD uint64_t fetch_cell(const VolumeView& v, const uint64_t* o2, int cx, int 
 
 // Emptiness level of the pyramid at voxel (mx,my,mz): 3 = its 64^3 cell is empty, 2 = its 16^3 cell, 1 = its
 // 4^3 cell, 0 = the 4^3 cell holds voxels (word = its occ1 bits).
-VRT_HD int lookup_level(const VolumeView& v, const uint64_t* o2, const uint64_t* o3, int mx, int my, int mz, uint64_t& word)
+template <class OP>
+VRT_HD int lookup_level(const VolumeView& v, OP o2, OP o3, int mx, int my, int mz, uint64_t& word)
 {
     int cx = mx >> 2, cy = my >> 2, cz = mz >> 2;
     int qx = cx >> 2, qy = cy >> 2, qz = cz >> 2;
@@ -124,6 +132,14 @@ VRT_HD int lookup_level(const VolumeView& v, const uint64_t* o2, const uint64_t*
     if (!((w2 >> cell_bit(cx, cy, cz)) & 1ull)) return 1;
     word = v.occ1[cx + (cy + cz * v.n1y) * v.n1x];
     return 0;
+}
+
+// The distance field is stored in 4x4x4 bricks of 64 bytes (one cache line per brick): the rays of a wave are a
+// voxel or two apart, so one gather touches a couple of lines instead of one line per lane.
+VRT_HD size_t df_index(const VolumeView& v, int x, int y, int z)
+{
+    size_t brick = (size_t)(x >> 2) + ((size_t)(y >> 2) + (size_t)(z >> 2) * (size_t)v.n1y) * (size_t)v.n1x;
+    return brick * 64u + cell_bit(x, y, z);
 }
 
 // ---- boxIntersection + DDA setup (frag:109-144) -------------------------------------------------------
@@ -173,30 +189,215 @@ VRT_HD uint32_t voxel_at(const VolumeView& v, int mx, int my, int mz)
     return v.vox[(size_t)mx + ((size_t)my + (size_t)mz * (size_t)v.H) * (size_t)v.W];
 }
 
-// one literal DDA iteration's advance (frag:164-170)
+VRT_HD uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { uint32_t m = a < b ? a : b; return m < c ? m : c; }
+
+// One literal DDA iteration's advance (frag:164-170).  sideDist is never negative, so the order of the
+// floats is the order of their bit patterns: mask_a = (side_a <= min(side_b, side_c)) == (bits_a == min3(bits)).
+// (Integer min/compare need no NaN canonicalisation, which halves the instruction count of this block.)
 #define VRT_DDA_STEP(S, MASK)                                                         \
     do {                                                                              \
-        bool m0_ = (S).sdx <= fminf((S).sdy, (S).sdz);                                \
-        bool m1_ = (S).sdy <= fminf((S).sdz, (S).sdx);                                \
-        bool m2_ = (S).sdz <= fminf((S).sdx, (S).sdy);                                \
+        uint32_t bx_ = f2u((S).sdx), by_ = f2u((S).sdy), bz_ = f2u((S).sdz);          \
+        uint32_t mn_ = umin3(bx_, by_, bz_);                                          \
+        bool m0_ = bx_ == mn_, m1_ = by_ == mn_, m2_ = bz_ == mn_;                    \
         (MASK) = (uint32_t)m0_ | ((uint32_t)m1_ << 1) | ((uint32_t)m2_ << 2);         \
-        if (m0_) { (S).sdx = (S).sdx + (S).dx; (S).mx += (S).sx; }                    \
-        if (m1_) { (S).sdy = (S).sdy + (S).dy; (S).my += (S).sy; }                    \
-        if (m2_) { (S).sdz = (S).sdz + (S).dz; (S).mz += (S).sz; }                    \
+        (S).sdx = m0_ ? (S).sdx + (S).dx : (S).sdx; (S).mx += m0_ ? (S).sx : 0;       \
+        (S).sdy = m1_ ? (S).sdy + (S).dy : (S).sdy; (S).my += m1_ ? (S).sy : 0;       \
+        (S).sdz = m2_ ? (S).sdz + (S).dz : (S).sdz; (S).mz += m2_ ? (S).sz : 0;       \
     } while (0)
 
 VRT_HD void finish(const DdaState& s, uint32_t material, uint32_t mask, uint32_t fetches, RayInt& r)
 {
     r.pos = s.p; r.side = mk3(s.sdx, s.sdy, s.sdz); r.delta = mk3(s.dx, s.dy, s.dz);
     r.sx = s.sx; r.sy = s.sy; r.sz = s.sz; r.mx = s.mx; r.my = s.my; r.mz = s.mz;
-    r.material = material; r.mask = mask; r.fetches = fetches;
+    r.material = material; r.mask = mask; r.fetches = fetches; r.dbg0 = 0; r.dbg1 = 0;
+}
+
+// ---- wavefront votes (device: the 64 lanes of a gfx950 wave; host tests: a single lane) ------------------
+
+VRT_HD bool wave_all(bool p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(p) != 0;
+#else
+    return p;
+#endif
+}
+VRT_HD bool wave_any(bool p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(p) != 0;
+#else
+    return p;
+#endif
+}
+// min over the active lanes of k (k <= 63), by binary search over ballots: 6 votes, no cross-lane data movement.
+VRT_HD uint32_t wave_min_u6(uint32_t k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t bit = 32u; bit != 0u; bit >>= 1)
+        if (__ballot(k < (m | bit)) == 0ull) m |= bit;
+    return m;
+#else
+    return k;
+#endif
 }
 
 // ---- literal traversals ---------------------------------------------------------------------------------
 
-template <int TRAV>
-VRT_HD void trace_literal(const VolumeView& v, const uint64_t* o2, f3 start, f3 dir, uint32_t maxSteps, RayInt& r)
+// DF (distance-field skip, wave-cooperative).  Profiling showed the per-iteration loops are bound by the
+// vector-memory pipe, not by arithmetic: one 64-lane byte gather per DDA iteration touches ~24 cache lines on
+// the bench frame and sits on the critical path of every iteration.  Here a second byte volume holds, per
+// empty voxel, the Chebyshev distance (capped at 63) to the nearest solid voxel; every DDA iteration moves at most one voxel along each axis, so from a voxel with clearance k the
+// next k-1 iterations cannot reach a solid voxel -- no memory test is needed for them (the walls of the volume
+// are handled by the per-axis distance to the wall the ray is heading for).
+// The lanes of a wave agree by ballot on the smallest clearance among them and run that many iterations of
+// pure ALU stepping (the same fp32 additions as the shader, hence bit-identical results), then look at
+// memory again.  Neighbouring rays have clearances within a voxel or two of each other, so the wave-wide
+// minimum costs little.  Finished lanes are masked off; the votes see live lanes only.
+template <class STATS>
+VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
+    DdaState s;
+    dda_setup(v, start, dir, s);
+    uint32_t mask = s.mask, material = 0, fetches = 0;
+    bool done = false;
+    uint32_t clear = 63u;
+    uint32_t i = 0;                                            // wave-uniform: every live lane has done i iterations
+    uint32_t n_outer = 0;
+    for (;;) {
+        n_outer++;
+        if (!done) {
+            if (i >= maxSteps || oob(v, s.mx, s.my, s.mz)) { done = true; fetches = i; }
+            else {
+                clear = v.df[df_index(v, s.mx, s.my, s.mz)];
+                st_lookup(stats);
+                if (clear == 0u) { material = voxel_at(v, s.mx, s.my, s.mz); fetches = i + 1u; done = true; }
+            }
+        }
+        if (wave_all(done)) break;
+        // iterations this lane can take blind: fewer than its clearance to the nearest solid voxel and no more
+        // than it takes to reach the volume wall it is heading for (each iteration moves <= 1 voxel per axis)
+        uint32_t k = 63u;
+        if (!done) {
+            int nx = s.sx > 0 ? v.W - s.mx : (s.sx < 0 ? s.mx + 1 : 63);
+            int ny = s.sy > 0 ? v.H - s.my : (s.sy < 0 ? s.my + 1 : 63);
+            int nz = s.sz > 0 ? v.D - s.mz : (s.sz < 0 ? s.mz + 1 : 63);
+            int n = nx < ny ? nx : ny; n = n < nz ? n : nz;
+            k = (uint32_t)n < clear ? (uint32_t)n : clear;
+        }
+        uint32_t kw = wave_min_u6(k);                          // >= 1: live lanes stand on empty in-bounds voxels
+        uint32_t left = maxSteps - i;                          // i < maxSteps for every live lane
+        kw = kw < left ? kw : left;
+        st_jump(stats, kw > 4u ? 2 : 1);
+        if (!done) {
+            // kw - 1 iterations whose mask nobody will read, then one that records it
+            for (uint32_t j = 1; j < kw; j++) {
+                uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+                uint32_t mn = umin3(bx, by, bz);
+                bool k0 = bx == mn, k1 = by == mn, k2 = bz == mn;
+                s.sdx = k0 ? s.sdx + s.dx : s.sdx; s.mx += k0 ? s.sx : 0;
+                s.sdy = k1 ? s.sdy + s.dy : s.sdy; s.my += k1 ? s.sy : 0;
+                s.sdz = k2 ? s.sdz + s.dz : s.sdz; s.mz += k2 ? s.sz : 0;
+            }
+            VRT_DDA_STEP(s, mask);
+        }
+        i += kw;
+    }
+    finish(s, material, mask, fetches, r);
+    r.dbg0 = n_outer;
+}
+
+// DENSE: one R8 fetch per iteration.  Straight-line body with a single exit (out of budget, out of bounds or
+// solid), the voxel index maintained incrementally in IDX (uint32_t for volumes below 4 GiB).
+template <class IDX>
+VRT_HD void trace_dense(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r)
+{
+    DdaState s;
+    dda_setup(v, start, dir, s);
+    uint32_t mask = s.mask, material = 0, i = 0;
+    IDX idx = (IDX)s.mx + (IDX)s.my * (IDX)v.W + (IDX)s.mz * (IDX)v.W * (IDX)v.H;   // meaningless (and unused) while out of bounds
+    const IDX incx = (IDX)(int64_t)s.sx, incy = (IDX)((int64_t)s.sy * (int64_t)v.W),
+              incz = (IDX)((int64_t)s.sz * (int64_t)v.W * (int64_t)v.H);
+    for (;;) {
+        bool stop = i >= maxSteps || oob(v, s.mx, s.my, s.mz);
+        uint32_t m = v.vox[stop ? (IDX)0 : idx];
+        if (stop || m != 0u) { material = stop ? 0u : m; break; }
+        ++i;
+        uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+        uint32_t mn = umin3(bx, by, bz);
+        bool m0 = bx == mn, m1 = by == mn, m2 = bz == mn;
+        mask = (uint32_t)m0 | ((uint32_t)m1 << 1) | ((uint32_t)m2 << 2);
+        s.sdx = m0 ? s.sdx + s.dx : s.sdx; s.mx += m0 ? s.sx : 0;
+        s.sdy = m1 ? s.sdy + s.dy : s.sdy; s.my += m1 ? s.sy : 0;
+        s.sdz = m2 ? s.sdz + s.dz : s.sdz; s.mz += m2 ? s.sz : 0;
+        idx += (m0 ? incx : (IDX)0) + (m1 ? incy : (IDX)0) + (m2 ? incz : (IDX)0);
+    }
+    finish(s, material, mask, material ? i + 1u : i, r);
+}
+
+// DENSE, latency-hiding form.  The DDA advance does not depend on the fetched voxel -- only the exit test
+// does -- so the march runs B iterations ahead with B fetches in flight, then looks for the first iteration
+// that should have stopped; if there is one, the saved state is replayed up to it with the same arithmetic.
+// One fetch latency (an L2 / Infinity-Cache hit, 200-550 cycles) is paid per B iterations instead of per
+// iteration; this is what shortens the critical path of the longest ray in a frame.
+template <int B>
+VRT_HD void trace_dense_blocked(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r)
+{
+    DdaState s;
+    dda_setup(v, start, dir, s);
+    uint32_t mask = s.mask, material = 0, i = 0;
+    uint32_t idx = (uint32_t)s.mx + (uint32_t)s.my * (uint32_t)v.W + (uint32_t)s.mz * (uint32_t)v.W * (uint32_t)v.H;
+    const uint32_t incx = (uint32_t)s.sx, incy = (uint32_t)(s.sy * v.W), incz = (uint32_t)(s.sz * v.W * v.H);
+    for (;;) {
+        // snapshot
+        const float s0x = s.sdx, s0y = s.sdy, s0z = s.sdz;
+        const int m0x = s.mx, m0y = s.my, m0z = s.mz;
+        const uint32_t mask0 = mask;
+        uint32_t vox[B];
+        uint32_t stopbits = 0;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            bool stop = (i + (uint32_t)b) >= maxSteps || oob(v, s.mx, s.my, s.mz);
+            stopbits |= (uint32_t)stop << b;
+            vox[b] = v.vox[stop ? 0u : idx];
+            uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+            uint32_t mn = umin3(bx, by, bz);
+            bool k0 = bx == mn, k1 = by == mn, k2 = bz == mn;
+            mask = (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2);
+            s.sdx = k0 ? s.sdx + s.dx : s.sdx; s.mx += k0 ? s.sx : 0;
+            s.sdy = k1 ? s.sdy + s.dy : s.sdy; s.my += k1 ? s.sy : 0;
+            s.sdz = k2 ? s.sdz + s.dz : s.sdz; s.mz += k2 ? s.sz : 0;
+            idx += (k0 ? incx : 0u) + (k1 ? incy : 0u) + (k2 ? incz : 0u);
+        }
+        uint32_t exitbits = stopbits;
+#pragma unroll
+        for (int b = 0; b < B; b++) exitbits |= (uint32_t)(vox[b] != 0u) << b;
+        if (exitbits == 0u) { i += (uint32_t)B; continue; }
+        // first iteration of the block that stops: replay the snapshot up to it
+        int first = 0;
+#pragma unroll
+        for (int b = B - 1; b >= 0; b--) if ((exitbits >> b) & 1u) first = b;
+        uint32_t m = 0;
+#pragma unroll
+        for (int b = 0; b < B; b++) if (b == first) m = vox[b];
+        material = ((stopbits >> first) & 1u) ? 0u : m;
+        s.sdx = s0x; s.sdy = s0y; s.sdz = s0z; s.mx = m0x; s.my = m0y; s.mz = m0z; mask = mask0;
+        for (int b = 0; b < first; b++) VRT_DDA_STEP(s, mask);
+        i += (uint32_t)first;
+        break;
+    }
+    finish(s, material, mask, material ? i + 1u : i, r);
+}
+
+template <int TRAV, class OP>
+VRT_HD void trace_literal(const VolumeView& v, OP o2, f3 start, f3 dir, uint32_t maxSteps, RayInt& r)
+{
+    if (TRAV == VRT_TRAVERSAL_DENSE) {
+        trace_dense_blocked<4>(v, start, dir, maxSteps, r);    // the API rejects DENSE for volumes of 4 GiB and more
+        return;
+    }
     DdaState s;
     dda_setup(v, start, dir, s);
     uint32_t mask = s.mask, material = 0, fetches = 0;
@@ -205,17 +406,12 @@ VRT_HD void trace_literal(const VolumeView& v, const uint64_t* o2, f3 start, f3 
     uint32_t i = 0;
     for (; i < maxSteps; i++) {
         if (oob(v, s.mx, s.my, s.mz)) break;
-        if (TRAV == VRT_TRAVERSAL_DENSE) {
+        uint32_t key = (uint32_t)(s.mx >> 2) | ((uint32_t)(s.my >> 2) << 10) | ((uint32_t)(s.mz >> 2) << 20);
+        if (key != ckey) { ckey = key; word = fetch_cell(v, o2, s.mx >> 2, s.my >> 2, s.mz >> 2); }
+        if ((word >> cell_bit(s.mx, s.my, s.mz)) & 1ull) {
             material = voxel_at(v, s.mx, s.my, s.mz);
-            if (material != 0) { fetches = i + 1; break; }
-        } else {
-            uint32_t key = (uint32_t)(s.mx >> 2) | ((uint32_t)(s.my >> 2) << 10) | ((uint32_t)(s.mz >> 2) << 20);
-            if (key != ckey) { ckey = key; word = fetch_cell(v, o2, s.mx >> 2, s.my >> 2, s.mz >> 2); }
-            if ((word >> cell_bit(s.mx, s.my, s.mz)) & 1ull) {
-                material = voxel_at(v, s.mx, s.my, s.mz);
-                fetches = i + 1;
-                break;
-            }
+            fetches = i + 1;
+            break;
         }
         VRT_DDA_STEP(s, mask);
     }
@@ -287,8 +483,8 @@ VRT_HD int jump_axis_apply(const JumpAxis& a, uint32_t Tstar, float d, float& si
 
 VRT_HD int iabs(int x) { return x < 0 ? -x : x; }
 
-template <class STATS>
-VRT_HD void trace_jump(const VolumeView& v, const uint64_t* o2, const uint64_t* o3, f3 start, f3 dir,
+template <class STATS, class OP>
+VRT_HD void trace_jump(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
                        uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -355,13 +551,16 @@ VRT_HD void trace_jump(const VolumeView& v, const uint64_t* o2, const uint64_t* 
 }
 
 // Dispatcher used by the kernels.
-template <int TRAV>
-VRT_HD void trace_int(const VolumeView& v, const uint64_t* o2, const uint64_t* o3, f3 start, f3 dir,
+template <int TRAV, class OP>
+VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
                       uint32_t maxSteps, RayInt& r)
 {
     if (TRAV == VRT_TRAVERSAL_JUMP) {
         NoStats ns;
         trace_jump(v, o2, o3, start, dir, maxSteps, r, ns);
+    } else if (TRAV == VRT_TRAVERSAL_DF) {
+        NoStats ns;
+        trace_df(v, start, dir, maxSteps, r, ns);
     } else {
         trace_literal<TRAV>(v, o2, start, dir, maxSteps, r);
     }

@@ -216,6 +216,10 @@ class Engine:
     def synchronize(self):
         check(lib().vrt_ctx_synchronize(self.ctx))
 
+    def set_timing(self, enabled: bool):
+        """Per-call HIP event recording inside the library (vrt_last_timings); off for throughput runs."""
+        check(lib().vrt_ctx_set_timing(self.ctx, 1 if enabled else 0))
+
     def last_timings(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         check(lib().vrt_last_timings(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
@@ -446,6 +450,23 @@ class GeometryStage:
         check(lib().vrt_render_geometry(self.engine.ctx, self._scene.handle, C.byref(push), C.byref(st), C.byref(fr),
                                         C.byref(shard) if shard is not None else None))
         return gb
+
+    def prepare(self, shard: Optional[_capi.Shard] = None):
+        """Frame loops whose settings do not change between frames: marshal the settings / target structs once and
+        return launch(push) -> GeometryBuffer (a Python-side economy only; the same C-ABI call is made)."""
+        gb = self._targets()
+        st, fr = self._settings.to_c(), gb.to_c()
+        fn, ctx, scene = lib().vrt_render_geometry, self.engine.ctx, self._scene.handle
+        pst, pfr = C.byref(st), C.byref(fr)
+        psh = C.byref(shard) if shard is not None else None
+
+        def launch(push: _capi.Push) -> GeometryBuffer:
+            rc = fn(ctx, scene, C.byref(push), pst, pfr, psh)
+            if rc != 0:
+                check(rc)
+            return gb
+        launch._keepalive = (st, fr, shard, gb)
+        return launch
 
 
 class DenoiserStage:
