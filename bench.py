@@ -143,8 +143,21 @@ def main():
         b_alg = (S_frame + W * H * B_OUT) * launches_share
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         tm = engine.last_timings()
+        # HBM bytes per K1 launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
+        # this same command; tools/pmc_summary.py -> profiles/*_k_primary_pmc.json).  Counters cannot be read from inside
+        # the process, so the committed summary is quoted, and only for the configuration it was collected on.
+        traffic, traffic_src = None, None
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k_primary_pmc.json")))
+        if pm and world == 1 and (W, H, NV) == (1920, 1080, 256) and args.traversal in ("AUTO", "DF"):
+            try:
+                pj = json.load(open(pm[-1]))
+                traffic = int(pj["hbm_bytes_per_launch"]["total_guide_rule"])
+                traffic_src = os.path.relpath(pm[-1], ROOT)
+            except Exception:
+                traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "k_primary", "kernel_ms": round(kern_ms, 5),
                     "algorithmic_bytes_per_launch": int(b_alg), "dda_steps_per_frame": S_frame,
                     "steps_per_ray": round(S_frame / (W * H), 2)}

@@ -416,6 +416,7 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     GeomParams p;
     memset(&p, 0, sizeof p);
     p.sc = s->d; p.pc = *push; p.st = *st; p.fr = *frame;
+    p.rg = raygen_consts(*push);
     int rc = make_shard(shard, H, p.sh, nullptr);
     if (rc != VRT_OK) return rc;
     p.tiles_x = ceil_div(W, 16);

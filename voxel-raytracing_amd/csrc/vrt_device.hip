@@ -206,17 +206,14 @@ __device__ __forceinline__ f3 random_dir(const DevScene& s, const vrt_push& pc, 
 }
 
 // main() ray generation, voxel_volume.frag:312-322 (+ screen_quad.vert:18-31)
-__device__ __forceinline__ f3 primary_dir(const vrt_push& pc, int px, int py)
+__device__ __forceinline__ f3 primary_dir(const GeomParams& P, int px, int py)
 {
-    float W = (float)pc.screen_size[0], H = (float)pc.screen_size[1];
-    float sx = (((float)px + 0.5f) / W) * 2.0f - 1.0f;
-    float sy = (((float)py + 0.5f) / H) * 2.0f - 1.0f;
-    f3 cd = normalize3(mk3(pc.cam_dir[0], pc.cam_dir[1], pc.cam_dir[2]));
-    float jx = (pc.camera_jitter[0] / W) * -2.0f;
-    float jy = (pc.camera_jitter[1] / H) * 2.0f;
-    float vx = ((cd.x + sx * pc.cam_right[0]) + sy * ((pc.cam_up[0] * H) / W)) + jx;
-    float vy = ((cd.y + sx * pc.cam_right[1]) + sy * ((pc.cam_up[1] * H) / W)) + jy;
-    float vz = ((cd.z + sx * pc.cam_right[2]) + sy * ((pc.cam_up[2] * H) / W)) + 0.0f;
+    const RayGenConsts& g = P.rg;
+    float sx = (((float)px + 0.5f) / g.W) * 2.0f - 1.0f;
+    float sy = (((float)py + 0.5f) / g.H) * 2.0f - 1.0f;
+    float vx = ((g.cd.x + sx * P.pc.cam_right[0]) + sy * g.planeV.x) + g.jx;
+    float vy = ((g.cd.y + sx * P.pc.cam_right[1]) + sy * g.planeV.y) + g.jy;
+    float vz = ((g.cd.z + sx * P.pc.cam_right[2]) + sy * g.planeV.z) + 0.0f;
     return normalize3(mk3(vx, vy, vz));
 }
 
@@ -371,7 +368,7 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
 
     const DevScene& s = P.sc;
     f3 start = mk3(P.pc.cam_pos[0], P.pc.cam_pos[1], P.pc.cam_pos[2]);
-    f3 dir = primary_dir(P.pc, px, py);
+    f3 dir = primary_dir(P, px, py);
     RayHit h; RayInt r;
     trace_ray<TRAV>(s, occ, start, dir, P.st.max_steps, h, r);
     bool hit = h.material != 0;
@@ -445,7 +442,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     uint4 rec = P.records[i];
     RayHit h;
     h.material = rec.w & 0xFFu;
-    h.dir = primary_dir(P.pc, px, py);
+    h.dir = primary_dir(P, px, py);
     h.pos = mk3(__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z));
     uint32_t mask = (rec.w >> 8) & 7u;
     int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;

@@ -29,7 +29,28 @@ struct ShardMap {
     int32_t tiles_per_strip;            // strip_rows / 16
 };
 
+// The pixel-independent part of main()'s ray generation (voxel_volume.frag:312-319), evaluated once on the host with
+// the same fp32 operations the shader performs per fragment.
+struct RayGenConsts {
+    f3 cd;             // normalize(camDir.xyz)
+    f3 planeV;         // camUp.xyz * H / W
+    float jx, jy;      // cameraJitter / screenSize * (-2, 2)
+    float W, H;
+};
+
+inline RayGenConsts raygen_consts(const vrt_push& pc)
+{
+    RayGenConsts g;
+    g.W = (float)pc.screen_size[0]; g.H = (float)pc.screen_size[1];
+    g.cd = normalize3(mk3(pc.cam_dir[0], pc.cam_dir[1], pc.cam_dir[2]));
+    g.planeV = mk3((pc.cam_up[0] * g.H) / g.W, (pc.cam_up[1] * g.H) / g.W, (pc.cam_up[2] * g.H) / g.W);
+    g.jx = (pc.camera_jitter[0] / g.W) * -2.0f;
+    g.jy = (pc.camera_jitter[1] / g.H) * 2.0f;
+    return g;
+}
+
 struct GeomParams {
+    RayGenConsts rg;
     DevScene   sc;
     vrt_push   pc;
     vrt_settings st;

@@ -141,6 +141,12 @@ VRT_HD size_t df_index(const VolumeView& v, int x, int y, int z)
     size_t brick = (size_t)(x >> 2) + ((size_t)(y >> 2) + (size_t)(z >> 2) * (size_t)v.n1y) * (size_t)v.n1x;
     return brick * 64u + cell_bit(x, y, z);
 }
+// same, for fields of less than 4 GiB (the common case: 32-bit address arithmetic in the traversal loop)
+VRT_HD uint32_t df_index32(const VolumeView& v, int x, int y, int z)
+{
+    uint32_t brick = (uint32_t)(x >> 2) + ((uint32_t)(y >> 2) + (uint32_t)(z >> 2) * (uint32_t)v.n1y) * (uint32_t)v.n1x;
+    return brick * 64u + cell_bit(x, y, z);
+}
 
 // ---- boxIntersection + DDA setup (frag:109-144) -------------------------------------------------------
 
@@ -264,6 +270,7 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
     uint32_t mask = s.mask, material = 0, fetches = 0;
     bool done = false;
     uint32_t clear = 63u;
+    const bool small = (uint64_t)v.n1x * (uint64_t)v.n1y * (uint64_t)v.n1z * 64ull <= 0xFFFFFFFFull;   // wave-uniform
     uint32_t i = 0;                                            // wave-uniform: every live lane has done i iterations
     uint32_t n_outer = 0;
     for (;;) {
@@ -271,9 +278,14 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
         if (!done) {
             if (i >= maxSteps || oob(v, s.mx, s.my, s.mz)) { done = true; fetches = i; }
             else {
-                clear = v.df[df_index(v, s.mx, s.my, s.mz)];
+                clear = small ? v.df[df_index32(v, s.mx, s.my, s.mz)] : v.df[df_index(v, s.mx, s.my, s.mz)];
                 st_lookup(stats);
-                if (clear == 0u) { material = voxel_at(v, s.mx, s.my, s.mz); fetches = i + 1u; done = true; }
+                if (clear == 0u) {
+                    material = small ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
+                                     : voxel_at(v, s.mx, s.my, s.mz);
+                    fetches = i + 1u;
+                    done = true;
+                }
             }
         }
         if (wave_all(done)) break;
