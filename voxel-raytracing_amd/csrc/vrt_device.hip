@@ -522,8 +522,32 @@ const char* primary_kernel_name(int traversal, int fused, int occ_lds)
 // ---------------------------------------------------------------------------------------------
 // K3: a-trous denoiser pass
 // ---------------------------------------------------------------------------------------------
+//
+// Same arithmetic as denoiser.frag:38-73 / the oracle, bit for bit, but with the work the values make
+// unnecessary left out:
+//   * UNORM8 / SNORM8 decode c/255, c/127: q0 = c*r, q = fma(fma(-D, q0, c), r, q0) with r = RN(1/D) equals the
+//     IEEE quotient for every one of the 256 codes (checked exhaustively in tests/test_denoise_decode.py);
+//     3 instructions instead of a ~12-instruction division sequence, 8 decodes per tap;
+//   * pass 0 has phi = 1/0 * phi0 = +inf, so every edge-stopping weight is min(exp(-0), 1) = 1 exactly
+//     (NaN / inf distances included: fminf ignores the NaN): the pass is specialised to a plain weighted blur;
+//   * a distance of exactly 0 gives exp(-0) = 1 and a quotient below -87 gives exp = 0 (vrt_spec.h exp_spec):
+//     neither needs the division + exponential; a zero weight makes the whole tap contribute +0.
+// One wave = 64 consecutive pixels of a row (coalesced 256 B / 1 KiB accesses).
 
 struct Guides { float c[4], n[4], p[4]; };
+
+__device__ __forceinline__ float decode_unorm8(uint32_t c)
+{
+    const float r = 1.0f / 255.0f;
+    float cf = (float)c, q0 = cf * r;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, q0, cf), r, q0);
+}
+__device__ __forceinline__ float decode_snorm8(int32_t c)
+{
+    const float r = 1.0f / 127.0f;
+    float cf = (float)c, q0 = cf * r;
+    return fmaxf(__builtin_fmaf(__builtin_fmaf(-127.0f, q0, cf), r, q0), -1.0f);
+}
 
 __device__ __forceinline__ void texel_guides(const DenoiseParams& P, int x, int y, Guides& g)
 {
@@ -533,9 +557,8 @@ __device__ __forceinline__ void texel_guides(const DenoiseParams& P, int x, int 
     uchar4 c = reinterpret_cast<const uchar4*>(P.color_in)[i];
     char4 n = reinterpret_cast<const char4*>(P.normal)[i];
     float4 p = reinterpret_cast<const float4*>(P.position)[i];
-    g.c[0] = (float)c.x / 255.0f; g.c[1] = (float)c.y / 255.0f; g.c[2] = (float)c.z / 255.0f; g.c[3] = (float)c.w / 255.0f;
-    g.n[0] = fmaxf((float)n.x / 127.0f, -1.0f); g.n[1] = fmaxf((float)n.y / 127.0f, -1.0f);
-    g.n[2] = fmaxf((float)n.z / 127.0f, -1.0f); g.n[3] = fmaxf((float)n.w / 127.0f, -1.0f);
+    g.c[0] = decode_unorm8(c.x); g.c[1] = decode_unorm8(c.y); g.c[2] = decode_unorm8(c.z); g.c[3] = decode_unorm8(c.w);
+    g.n[0] = decode_snorm8(n.x); g.n[1] = decode_snorm8(n.y); g.n[2] = decode_snorm8(n.z); g.n[3] = decode_snorm8(n.w);
     g.p[0] = p.x; g.p[1] = p.y; g.p[2] = p.z; g.p[3] = p.w;
 }
 
@@ -563,6 +586,16 @@ __device__ __forceinline__ float dist2_4(const float* a, const float* b)
     return ((t0 * t0 + t1 * t1) + t2 * t2) + t3 * t3;
 }
 
+// min(exp(-(d2)/phi), 1) (denoiser.frag:55,60,65) for a finite phi > 0, skipping the division and the exponential
+// when the value of d2 already decides the result.
+__device__ __forceinline__ float edge_weight(float d2, float phi)
+{
+    if (d2 == 0.0f) return 1.0f;                      // (-0)/phi = -0, exp(-0) = 1
+    float x = (-d2) / phi;
+    if (x < -87.0f) return 0.0f;                      // exp_spec's own cut-off
+    return fminf(exp_spec(x), 1.0f);
+}
+
 // Row mapping shared by the denoiser and the strip copy kernels: local row index -> frame row.
 __device__ __forceinline__ int strip_row(const ShardMap& sh, int extend, int r, int H)
 {
@@ -575,7 +608,7 @@ __device__ __forceinline__ int strip_row(const ShardMap& sh, int extend, int r, 
     return y;
 }
 
-// denoiser.frag:38-73.  One wave = 64 consecutive pixels of one row (coalesced 256 B / 1 KiB accesses).
+template <bool PHI_INF>
 __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
 {
     int px = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -583,40 +616,38 @@ __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
     int py = strip_row(P.sh, P.extend, r, P.H);
     if (py < 0 || px >= P.W) return;
 
-    float kern[9], offx[9], offy[9];
-    int ntaps;
-    if (P.mode == VRT_DENOISE_AS_SHIPPED) {
-        ntaps = 3;
-        kern[0] = kGauss2; offx[0] = -1.0f; offy[0] = -1.0f;
-        kern[1] = kGauss0; offx[1] = 1.0f;  offy[1] = -1.0f;
-        kern[2] = kGauss2; offx[2] = 0.0f;  offy[2] = 0.0f;
-    } else {
-        ntaps = 9;
-        for (int i = 0, y = -1; y <= 1; y++)
-            for (int x = -1; x <= 1; x++, i++) {
-                offx[i] = (float)x; offy[i] = (float)y;
-                int r2 = x * x + y * y;
-                kern[i] = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2);
-            }
-    }
+    const bool shipped = P.mode == VRT_DENOISE_AS_SHIPPED;
+    const int ntaps = shipped ? 3 : 9;
     float sw = P.step_width;
+    float sw2 = sw * sw;
     Guides s, o;
     texel_guides(P, px, py, s);
     float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float total = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        if (i >= ntaps) break;
-        sample_guides(P, px, py, offx[i] * sw, offy[i] * sw, o);
-        float d2 = dist2_4(s.c, o.c);
-        float cw = fminf(exp_spec((-d2) / P.phi_color), 1.0f);
-        d2 = fmaxf(dist2_4(s.n, o.n) / (sw * sw), 0.0f);
-        float nw = fminf(exp_spec((-d2) / P.phi_normal), 1.0f);
-        d2 = dist2_4(s.p, o.p);
-        float pw = fminf(exp_spec((-d2) / P.phi_pos), 1.0f);
-        float w = (cw * nw) * pw;
-        for (int k = 0; k < 4; k++) sum[k] += (o.c[k] * w) * kern[i];
-        total += w * kern[i];
+    for (int i = 0; i < ntaps; i++) {
+        int tx, ty; float kern;
+        if (shipped) {        // std140 aliasing: taps (-1,-1)*G2, (1,-1)*G0, (0,0)*G2
+            tx = i == 0 ? -1 : (i == 1 ? 1 : 0); ty = i == 2 ? 0 : -1;
+            kern = i == 1 ? kGauss0 : kGauss2;
+        } else {
+            tx = i % 3 - 1; ty = i / 3 - 1;
+            int r2 = tx * tx + ty * ty;
+            kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2);
+        }
+        sample_guides(P, px, py, (float)tx * sw, (float)ty * sw, o);
+        float w = 1.0f;
+        if (!PHI_INF) {
+            float pw = edge_weight(dist2_4(s.p, o.p), P.phi_pos);
+            float cw = 1.0f, nw = 1.0f;
+            if (pw != 0.0f) {                         // a zero factor makes w = +0 whatever the other two are (all finite)
+                cw = edge_weight(dist2_4(s.c, o.c), P.phi_color);
+                float dn = dist2_4(s.n, o.n);
+                nw = dn == 0.0f ? 1.0f : edge_weight(fmaxf(dn / sw2, 0.0f), P.phi_normal);
+            }
+            w = (cw * nw) * pw;
+        }
+        for (int k = 0; k < 4; k++) sum[k] += (o.c[k] * w) * kern;
+        total += w * kern;
     }
     uchar4 out;
     out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
@@ -628,7 +659,10 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
 {
     int rows = p.sh.n_local_strips * (p.sh.strip_rows + 2 * p.extend);
     dim3 grid((unsigned)((p.W + 63) / 64), (unsigned)((rows + 3) / 4)), block(256);
-    hipLaunchKernelGGL(k_denoise, grid, block, 0, s, p);
+    // phi = +inf in all three channels <=> pass 0 (denoiser_stage.cpp:148-150)
+    bool inf = __builtin_isinf(p.phi_color) && __builtin_isinf(p.phi_normal) && __builtin_isinf(p.phi_pos);
+    if (inf) hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, s, p);
+    else     hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, s, p);
     return hipGetLastError();
 }
 
