@@ -66,6 +66,7 @@ typedef struct vrt_push {
 #define VRT_TRAVERSAL_JUMP    3   /* BITMASK + exact closed-form jumps across empty pyramid cells */
 #define VRT_TRAVERSAL_DF      4   /* distance-field clearance agreed per wave by ballot; ALU-only runs between fetches */
 
+#define VRT_FLAG_SPLIT_KERNELS 4u /* trace secondary rays in a second kernel (K2) over the compacted hit list instead of inside K1 */
 #define VRT_FLAG_DEBUG_PLANES 1u  /* steps_total / rays_total receive traversal diagnostics instead (development aid) */
 
 /* VolumeParameters (parameters.hpp:5-9) + Light (voxel_scene.hpp:10-15) as GeometryStage::record fills

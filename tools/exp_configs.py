@@ -8,13 +8,14 @@ vol = vrt.synthetic.treehouse(256, seed=2)
 pal = vrt.synthetic.default_palette(metallic_ids=range(200, 256))
 sc = vrt.VoxelScene.from_dense(eng, vol, pal, sky=vrt.synthetic.sky_gradient(512, 256), noise=vrt.synthetic.blue_noise_standin(512))
 res = (1920, 1080)
-def run(name, ao, shadows, bounces, iters, trav="AUTO", reps=6):
+def run(name, ao, shadows, bounces, iters, trav="AUTO", reps=6, split=False):
     st = vrt.VoxelRenderSettings(targetResolution=res)
     st.fsrSetttings.enable = False
     st.occlusionSettings.numSamples = ao
     st.traceSettings.shadows = shadows
     st.traceSettings.maxReflections = bounces
     st.traceSettings.traversal = getattr(vrt, "TRAVERSAL_" + trav)
+    st.traceSettings.splitKernels = split
     st.denoiserSettings.enable = iters > 0
     st.denoiserSettings.iterations = max(iters, 1)
     r = vrt.VoxelRenderer(eng, st, sc)
@@ -33,3 +34,5 @@ for trav in sys.argv[1:] or ["AUTO"]:
     run("config3 +shadow +2 denoise passes", 0, True, 0, 2, trav)
     run("AO4 + shadow, no bounce, 2 passes", 4, True, 0, 2, trav)
     run("reference defaults (AO4,5 bounces)", 4, True, 5, 2, trav)
+    run("config3 split kernels", 0, True, 0, 2, trav, split=True)
+    run("defaults split kernels", 4, True, 5, 2, trav, split=True)

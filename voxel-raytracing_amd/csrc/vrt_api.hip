@@ -42,6 +42,7 @@ struct vrt_ctx {
     hipEvent_t ev_geo0 = nullptr, ev_prim1 = nullptr, ev_geo1 = nullptr, ev_den0 = nullptr, ev_den1 = nullptr;
     bool have_geo = false, have_den = false;
     uint4* records = nullptr;
+    uint32_t* hit_list = nullptr;     // [records_px] + 1 counter word at the end
     size_t records_px = 0;
 };
 
@@ -85,6 +86,7 @@ void vrt_ctx_destroy(vrt_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->records) hipFree(c->records);
+    if (c->hit_list) hipFree(c->hit_list);
     hipEventDestroy(c->ev_geo0); hipEventDestroy(c->ev_prim1); hipEventDestroy(c->ev_geo1);
     hipEventDestroy(c->ev_den0); hipEventDestroy(c->ev_den1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -423,7 +425,8 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     p.tiles_y_local = p.sh.n_local_strips * p.sh.tiles_per_strip;
     p.total_tiles = p.tiles_x * p.tiles_y_local;
     p.chunk = p.tiles_x * ceil_div(p.tiles_y_local, 8);      // workgroups per XCD slot (tile rows are dealt round-robin)
-    p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : 0;
+    // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
+    p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
     p.occ2_bytes = s->occ2_bytes; p.occ3_bytes = s->occ3_bytes;
     p.occ_in_lds = ((size_t)s->occ2_bytes + s->occ3_bytes <= 65536) ? 1 : 0;
     if (!p.fused_shade) {
@@ -431,11 +434,16 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
         if (c->records_px < px) {
             HIPCHK(hipStreamSynchronize(c->stream));
             if (c->records) hipFree(c->records);
-            c->records = nullptr; c->records_px = 0;
+            if (c->hit_list) hipFree(c->hit_list);
+            c->records = nullptr; c->hit_list = nullptr; c->records_px = 0;
             HIPCHK(hipMalloc((void**)&c->records, px * sizeof(uint4)));
+            HIPCHK(hipMalloc((void**)&c->hit_list, (px + 1) * sizeof(uint32_t)));
             c->records_px = px;
         }
         p.records = c->records;
+        p.hit_list = c->hit_list;
+        p.hit_count = c->hit_list + c->records_px;
+        HIPCHK(hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), c->stream));
     }
     if (p.total_tiles == 0) return VRT_OK;
     if (c->timing) HIPCHK(hipEventRecord(c->ev_geo0, c->stream));

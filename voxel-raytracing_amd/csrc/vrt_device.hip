@@ -348,10 +348,15 @@ template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomPara
 // K1: primary rays
 // ---------------------------------------------------------------------------------------------
 
-template <int TRAV, bool OCC_LDS, bool FUSED>
+// MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;
+// MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
+//         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
+//         single round of waves and is bound by the longest ray's dependency chain).
+template <int TRAV, bool OCC_LDS, int MODE>
 __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
+    const uint64_t t_begin = (P.st.flags & 2u) ? wall_clock64() : 0ull;      // diagnostic timeline (100 MHz)
     int x0, y0;
     bool live = tile_origin(P, x0, y0);          // uniform per workgroup
     if (!live) return;
@@ -394,13 +399,21 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
     if (f.steps_primary) f.steps_primary[i] = r.fetches;
     if (f.steps_total) f.steps_total[i] = (P.st.flags & VRT_FLAG_DEBUG_PLANES) ? r.dbg0 : r.fetches;
     if (f.rays_total) f.rays_total[i] = (P.st.flags & VRT_FLAG_DEBUG_PLANES) ? r.dbg1 : 1u;
+    if ((P.st.flags & 2u) && f.steps_total && f.rays_total) {             // wave start / end stamps, 10 ns units
+        f.steps_total[i] = (uint32_t)t_begin;
+        f.rays_total[i] = (uint32_t)wall_clock64();
+    }
 
-    if (FUSED) {
-        // no secondary rays enabled: shade here (ambient = 1, not shadowed, reflection = 0)
+    if (MODE != 0) {
         f3 col;
         if (hit) {
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
-            col = color_hit<TRAV>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);
+            if (MODE == 1) col = color_hit<TRAV>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
+            else {
+                col = color_main_ray<TRAV>(P, occ, c, h);
+                if (f.steps_total && !(P.st.flags & 3u)) f.steps_total[i] = r.fetches + c.fetches;
+                if (f.rays_total && !(P.st.flags & 3u)) f.rays_total[i] = 1u + c.rays;
+            }
         } else {
             col = sky_color(s, dir);
         }
@@ -409,11 +422,23 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
             uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
             reinterpret_cast<uchar4*>(f.color8)[i] = c8;
         }
-    } else {
-        // hit record for K2: position bits + material | mask << 8 | (step+1) codes
+    } else if (hit) {
+        // hit record for K2 (position bits + material | mask << 8 | (step+1) codes) and a slot in the compacted list of
+        // hit pixels: K2 then runs one lane per HIT pixel instead of one per pixel (hipcc folds the per-lane
+        // atomicAdd into one atomic per wave)
         uint32_t packed = h.material | (r.mask << 8) | ((uint32_t)(r.sx + 1) << 11) | ((uint32_t)(r.sy + 1) << 13) |
                           ((uint32_t)(r.sz + 1) << 15);
         P.records[i] = make_uint4(__float_as_uint(h.pos.x), __float_as_uint(h.pos.y), __float_as_uint(h.pos.z), packed);
+        uint32_t slot = atomicAdd(P.hit_count, 1u);
+        P.hit_list[slot] = (uint32_t)i;
+    } else {
+        // misses are final here: colorMainRay is never reached (voxel_volume.frag:337-345)
+        f3 col = sky_color(s, dir);
+        if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
+        if (f.color8) {
+            uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
+            reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+        }
     }
 }
 
@@ -425,20 +450,16 @@ template <int TRAV, bool OCC_LDS>
 __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
-    int x0, y0;
-    bool live = tile_origin(P, x0, y0);
-    if (!live) return;
     constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
+    uint32_t count = *P.hit_count;                        // written by K1 (previous kernel on the stream)
+    if (blockIdx.x * 256u >= count) return;               // uniform per workgroup
     const OccT<kLds> occ = stage_occ<kLds>(P, lds_occ);
+    uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= count) return;
+    size_t i = P.hit_list[gid];
+    int W = P.pc.screen_size[0];
+    int px = (int)(i % (size_t)W), py = (int)(i / (size_t)W);
 
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int px = x0 + (wave & 1) * 8 + (lane & 7);
-    int py = y0 + (wave >> 1) * 8 + (lane >> 3);
-    int W = P.pc.screen_size[0], H = P.pc.screen_size[1];
-    if (px >= W || py >= H) return;
-    size_t i = (size_t)py * (size_t)W + (size_t)px;
-
-    const DevScene& s = P.sc;
     uint4 rec = P.records[i];
     RayHit h;
     h.material = rec.w & 0xFFu;
@@ -447,14 +468,8 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     uint32_t mask = (rec.w >> 8) & 7u;
     int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;
     PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
-    f3 col;
-    if (h.material != 0) {
-        h.normal = hit_normal(mask, sx, sy, sz);
-        col = color_main_ray<TRAV>(P, occ, c, h);
-    } else {
-        h.normal = mk3(0.0f, 0.0f, 0.0f);
-        col = sky_color(s, h.dir);
-    }
+    h.normal = hit_normal(mask, sx, sy, sz);
+    f3 col = color_main_ray<TRAV>(P, occ, c, h);
     const vrt_frame& f = P.fr;
     if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
     if (f.color8) {
@@ -474,15 +489,18 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
     dim3 grid((unsigned)(p.chunk * 8)), block(256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
-    if (p.fused_shade) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, true>), grid, block, lds, s, p);
-    else               hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, false>), grid, block, lds, s, p);
+    if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1>), grid, block, lds, s, p);
+    else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2>), grid, block, lds, s, p);
+    else                         hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 0>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
 template <int TRAV, bool OCC_LDS>
 static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 {
-    dim3 grid((unsigned)(p.chunk * 8)), block(256);
+    // one lane per hit pixel of the compacted list; sized for the worst case (every local pixel hit), surplus
+    // workgroups leave at once
+    dim3 grid((unsigned)p.total_tiles), block(256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     hipLaunchKernelGGL((k_shade<TRAV, OCC_LDS>), grid, block, lds, s, p);
     return hipGetLastError();

@@ -58,6 +58,8 @@ struct GeomParams {
     ShardMap   sh;
     int32_t    tiles_x, tiles_y_local, total_tiles, chunk;  // chunk = tiles per XCD slot
     uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)
+    uint32_t*  hit_count;      // K1 -> K2: number of hit pixels (zeroed before K1)
+    uint32_t*  hit_list;       // K1 -> K2: their pixel indices, in arrival order
     int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled)
     int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
     uint32_t   occ2_bytes, occ3_bytes;   // both multiples of 16

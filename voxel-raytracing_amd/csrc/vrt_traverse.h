@@ -271,8 +271,10 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
     bool done = false;
     uint32_t clear = 63u;
     const bool small = (uint64_t)v.n1x * (uint64_t)v.n1y * (uint64_t)v.n1z * 64ull <= 0xFFFFFFFFull;   // wave-uniform
+    const float kInf = u2f(0x7F800000u);
+    const float adx = fabsf(dir.x), ady = fabsf(dir.y), adz = fabsf(dir.z);
     uint32_t i = 0;                                            // wave-uniform: every live lane has done i iterations
-    uint32_t n_outer = 0;
+    uint32_t n_outer = 0, n_long = 0;
     for (;;) {
         n_outer++;
         if (!done) {
@@ -303,22 +305,38 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
         uint32_t left = maxSteps - i;                          // i < maxSteps for every live lane
         kw = kw < left ? kw : left;
         st_jump(stats, kw > 4u ? 2 : 1);
+        if (kw >= 12u) n_long += kw;
         if (!done) {
+            // Only sideDist is advanced inside the run (10 VALU ops per iteration); mapPos is recovered afterwards:
+            // an axis that took n steps has grown by n (+) additions of delta, so n = rint((side - side_before) / delta)
+            // -- n <= 63 per run and the accumulated rounding error is orders of magnitude below 1/2.
+            const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
             // kw - 1 iterations whose mask nobody will read, then one that records it
             for (uint32_t j = 1; j < kw; j++) {
                 uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
                 uint32_t mn = umin3(bx, by, bz);
-                bool k0 = bx == mn, k1 = by == mn, k2 = bz == mn;
-                s.sdx = k0 ? s.sdx + s.dx : s.sdx; s.mx += k0 ? s.sx : 0;
-                s.sdy = k1 ? s.sdy + s.dy : s.sdy; s.my += k1 ? s.sy : 0;
-                s.sdz = k2 ? s.sdz + s.dz : s.sdz; s.mz += k2 ? s.sz : 0;
+                s.sdx = bx == mn ? s.sdx + s.dx : s.sdx;
+                s.sdy = by == mn ? s.sdy + s.dy : s.sdy;
+                s.sdz = bz == mn ? s.sdz + s.dz : s.sdz;
             }
-            VRT_DDA_STEP(s, mask);
+            {
+                uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+                uint32_t mn = umin3(bx, by, bz);
+                bool k0 = bx == mn, k1 = by == mn, k2 = bz == mn;
+                mask = (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2);
+                s.sdx = k0 ? s.sdx + s.dx : s.sdx;
+                s.sdy = k1 ? s.sdy + s.dy : s.sdy;
+                s.sdz = k2 ? s.sdz + s.dz : s.sdz;
+            }
+            // |dir| is 1/delta to within an ulp; axes that cannot step (dir = 0 or 1/dir overflowed) stay put
+            if (s.sx != 0 && s.dx < kInf) s.mx += s.sx * (int)rintf((s.sdx - ox) * adx);
+            if (s.sy != 0 && s.dy < kInf) s.my += s.sy * (int)rintf((s.sdy - oy) * ady);
+            if (s.sz != 0 && s.dz < kInf) s.mz += s.sz * (int)rintf((s.sdz - oz) * adz);
         }
         i += kw;
     }
     finish(s, material, mask, fetches, r);
-    r.dbg0 = n_outer;
+    r.dbg0 = n_outer; r.dbg1 = n_long;
 }
 
 // DENSE: one R8 fetch per iteration.  Straight-line body with a single exit (out of budget, out of bounds or

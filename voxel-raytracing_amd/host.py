@@ -80,6 +80,7 @@ class TraceSettings:
     maxReflections: int = 5
     shadows: bool = True
     traversal: int = _capi.TRAVERSAL_AUTO
+    splitKernels: bool = False         # K1 + K2 over the compacted hit list instead of the megakernel
 
 
 def _scale(scaling: FsrScaling, dim: int) -> int:      # voxel_render_settings.cpp:3-6
@@ -114,7 +115,7 @@ class VoxelRenderSettings:               # :44-59
         s.max_steps, s.ao_steps, s.max_bounces = int(t.maxRaySteps), int(t.aoSteps), int(t.maxReflections)
         s.shadows = 1 if t.shadows else 0
         s.traversal = int(t.traversal)
-        s.flags = 0
+        s.flags = 4 if t.splitKernels else 0
         return s
 
     def denoiser_to_c(self) -> _capi.DenoiserSettings:
