@@ -41,31 +41,37 @@ void* th_create(const uint8_t* vox, int W, int H, int D)
             h->o1[(size_t)(x >> 2) + ((size_t)(y >> 2) + (size_t)(z >> 2) * v.n1y) * v.n1x] |= 1ull << cell_bit(x, y, z);
     build_up(h->o1, v.n1x, v.n1y, v.n1z, h->o2, v.n2x, v.n2y, v.n2z);
     build_up(h->o2, v.n2x, v.n2y, v.n2z, h->o3, v.n3x, v.n3y, v.n3z);
-    // distance field: three 1-D min-max passes (same definition as k_df_pass, written independently)
+    // clearance fields: per octant three one-sided 1-D min-max passes (same definition as k_df_pass, written independently)
     {
         const int CAP = 63;
+        size_t stride = (size_t)v.n1x * v.n1y * v.n1z * 64;
+        h->df.assign(8 * stride, 0);
         std::vector<uint8_t> a((size_t)W * H * D), b((size_t)W * H * D);
-        for (size_t i = 0; i < a.size(); i++) a[i] = h->vox[i] ? 0 : CAP + 1;
-        for (int axis = 0; axis < 3; axis++) {
+        for (int o = 0; o < 8; o++) {
+            int sg[3] = {(o & 1) ? 1 : -1, (o & 2) ? 1 : -1, (o & 4) ? 1 : -1};
+            for (size_t i = 0; i < a.size(); i++) a[i] = h->vox[i] ? 0 : CAP + 1;
+            for (int axis = 0; axis < 3; axis++) {
+                for (int z = 0; z < D; z++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+                    size_t i = (size_t)x + ((size_t)y + (size_t)z * H) * W;
+                    int pos = axis == 0 ? x : (axis == 1 ? y : z), dim = axis == 0 ? W : (axis == 1 ? H : D);
+                    long long st = (axis == 0 ? 1 : (axis == 1 ? (long long)W : (long long)W * H)) * sg[axis];
+                    int best = a[i];
+                    for (int t = 1; t < best; t++) {
+                        int q = pos + t * sg[axis];
+                        int val = (q < 0 || q >= dim) ? CAP + 1 : a[(long long)i + t * st];
+                        int m = val > t ? val : t;
+                        if (m < best) best = m;
+                    }
+                    b[i] = (uint8_t)best;
+                }
+                a.swap(b);
+            }
             for (int z = 0; z < D; z++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
                 size_t i = (size_t)x + ((size_t)y + (size_t)z * H) * W;
-                int pos = axis == 0 ? x : (axis == 1 ? y : z), dim = axis == 0 ? W : (axis == 1 ? H : D);
-                size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)W : (size_t)W * H);
-                int best = a[i];
-                for (int t = 1; t < best; t++) {
-                    int lo = pos - t < 0 ? CAP + 1 : a[i - t * stride], hi = pos + t >= dim ? CAP + 1 : a[i + t * stride];
-                    int m = lo < hi ? lo : hi; if (m < t) m = t;
-                    if (m < best) best = m;
-                }
-                b[i] = (uint8_t)best;
+                h->df[(size_t)o * stride + df_index(v, x, y, z)] = a[i] > CAP ? CAP : a[i];
             }
-            a.swap(b);
         }
-        h->df.assign((size_t)v.n1x * v.n1y * v.n1z * 64, 0);
-        for (int z = 0; z < D; z++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
-            size_t i = (size_t)x + ((size_t)y + (size_t)z * H) * W;
-            h->df[df_index(v, x, y, z)] = a[i] > CAP ? CAP : a[i];
-        }
+        v.df_stride = stride;
     }
     v.df = h->df.data();
     v.vox = h->vox.data(); v.occ1 = h->o1.data(); v.occ2 = h->o2.data(); v.occ3 = h->o3.data();

@@ -243,23 +243,24 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     SCHK(hipMalloc((void**)&s->occ2, n2pad * 8));
     SCHK(hipMalloc((void**)&s->occ3, n3pad * 8));
     SCHK(hipMalloc((void**)&s->palette, 256 * sizeof(vrt_material)));
-    SCHK(hipMalloc((void**)&s->df, ndf));
-    SCHK(hipMemsetAsync(s->df, 0, ndf, c->stream));
+    SCHK(hipMalloc((void**)&s->df, 8 * ndf));
+    SCHK(hipMemsetAsync(s->df, 0, 8 * ndf, c->stream));
     SCHK(hipMemsetAsync(s->occ2, 0, n2pad * 8, c->stream));
     SCHK(hipMemsetAsync(s->occ3, 0, n3pad * 8, c->stream));
     SCHK(hipMemcpyAsync(s->vox, voxels, nvox, hipMemcpyHostToDevice, c->stream));
     SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_build_pyramid(s->vox, d.W, d.H, d.D, s->occ1, s->occ2, s->occ3, c->stream));
     {
-        uint8_t* tmp = nullptr;                                   // ping-pong buffer of the 3-pass distance transform
-        SCHK(hipMalloc((void**)&tmp, nvox));
-        hipError_t df_launch = launch_build_df(s->vox, d.W, d.H, d.D, s->df, tmp, c->stream);
+        uint8_t *tmp0 = nullptr, *tmp1 = nullptr;               // ping-pong buffers of the 3-pass transforms
+        SCHK(hipMalloc((void**)&tmp0, nvox));
+        hipError_t tmp1_alloc = hipMalloc((void**)&tmp1, nvox);
+        hipError_t df_launch = tmp1_alloc == hipSuccess ? launch_build_df(s->vox, d.W, d.H, d.D, s->df, ndf, tmp0, tmp1, c->stream) : tmp1_alloc;
         hipError_t df_sync = hipStreamSynchronize(c->stream);
-        hipFree(tmp);
+        hipFree(tmp0); if (tmp1) hipFree(tmp1);
         SCHK(df_launch); SCHK(df_sync);
     }
 #undef SCHK
-    d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.df = s->df; s->d.palette = s->palette;
+    d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.df = s->df; d.df_stride = ndf; s->d.palette = s->palette;
     s->occ2_bytes = (uint32_t)(n2pad * 8); s->occ3_bytes = (uint32_t)(n3pad * 8);
     {
         const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};

@@ -83,15 +83,18 @@ hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// distance field (scene build): Chebyshev distance to the nearest solid voxel,
-// d(p) = min_q max(|dx|,|dy|,|dz|) = min_dz max(|dz|, min_dy max(|dy|, min_dx |dx|)): three 1-D min-max passes.
+// clearance fields (scene build).  For octant o = (sx, sy, sz) in {-1,+1}^3, c_o(p) = side of the largest empty
+// cube with corner p extending towards (sx, sy, sz), 0 for a solid voxel, capped at 63:
+//   c(p) = min_{c>=0} max(c, min_{b>=0} max(b, min_{a>=0} max(a, solid(p + (a sx, b sy, c sz)) ? 0 : INF)))
+// i.e. three one-sided 1-D min-max passes.  Outside the volume counts as empty (the traversal bounds the run by
+// the distance to the wall separately).
 // ---------------------------------------------------------------------------------------------
 
 #define VRT_DF_CAP 63
 
-// src == nullptr: first pass, the field is (vox != 0 ? 0 : INF).  Outside the volume counts as empty.
+// src == nullptr: first pass, the field is (vox != 0 ? 0 : INF).
 __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox, const uint8_t* __restrict__ src,
-                                                 uint8_t* __restrict__ dst, int W, int H, int D, int axis, int bricked)
+                                                 uint8_t* __restrict__ dst, int W, int H, int D, int axis, int dir, int bricked)
 {
     size_t n = (size_t)W * H * D;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,13 +102,13 @@ __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox
     int x = (int)(i % (size_t)W), y = (int)((i / (size_t)W) % (size_t)H), z = (int)(i / ((size_t)W * H));
     int pos = axis == 0 ? x : (axis == 1 ? y : z);
     int dim = axis == 0 ? W : (axis == 1 ? H : D);
-    size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)W : (size_t)W * H);
+    long long stride = (axis == 0 ? 1 : (axis == 1 ? (long long)W : (long long)W * H)) * dir;
     int best = src ? (int)src[i] : (vox[i] != 0 ? 0 : VRT_DF_CAP + 1);
     for (int t = 1; t < best; t++) {
-        int lo = pos - t < 0 ? VRT_DF_CAP + 1 : (src ? (int)src[i - (size_t)t * stride] : (vox[i - (size_t)t * stride] != 0 ? 0 : VRT_DF_CAP + 1));
-        int hi = pos + t >= dim ? VRT_DF_CAP + 1 : (src ? (int)src[i + (size_t)t * stride] : (vox[i + (size_t)t * stride] != 0 ? 0 : VRT_DF_CAP + 1));
-        int m = lo < hi ? lo : hi;
-        m = m > t ? m : t;
+        int q = pos + t * dir;
+        int val = (q < 0 || q >= dim) ? VRT_DF_CAP + 1
+                                      : (src ? (int)src[(long long)i + t * stride] : (vox[(long long)i + t * stride] != 0 ? 0 : VRT_DF_CAP + 1));
+        int m = val > t ? val : t;
         best = best < m ? best : m;
     }
     size_t o = i;
@@ -116,15 +119,17 @@ __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox
     dst[o] = (uint8_t)(best > VRT_DF_CAP ? VRT_DF_CAP : best);
 }
 
-hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, uint8_t* tmp, hipStream_t s)
+// df: 8 * stride bytes (stride = bricked size of one field, >= W*H*D); tmp0/tmp1: W*H*D bytes each
+hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s)
 {
     size_t n = (size_t)W * H * D;
     unsigned blocks = (unsigned)((n + 255) / 256);
-    // pass values stay <= CAP + 1 = 64 until the final clamp, which every pass applies (harmless: min-max of
-    // clamped fields equals the clamped min-max)
-    hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)nullptr, df, W, H, D, 0, 0);
-    hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)df, tmp, W, H, D, 1, 0);
-    hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp, df, W, H, D, 2, 1);
+    for (int o = 0; o < 8; o++) {
+        int sx = (o & 1) ? 1 : -1, sy = (o & 2) ? 1 : -1, sz = (o & 4) ? 1 : -1;
+        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)nullptr, tmp0, W, H, D, 0, sx, 0);
+        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp0, tmp1, W, H, D, 1, sy, 0);
+        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp1, df + (size_t)o * stride, W, H, D, 2, sz, 1);
+    }
     return hipGetLastError();
 }
 

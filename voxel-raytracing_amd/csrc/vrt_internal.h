@@ -15,7 +15,8 @@ namespace vrt {
 //   vol.occ1  one u64 per 4^3 voxels  : bit (x&3) | (y&3)<<2 | (z&3)<<4 set <=> voxel != 0      [n1x*n1y*n1z]
 //   vol.occ2  one u64 per 16^3 voxels : bit over the 4x4x4 occ1 words, set <=> word != 0        [n2x*n2y*n2z]
 //   vol.occ3  one u64 per 64^3 voxels : same over occ2                                           [n3x*n3y*n3z]
-//   vol.df    W*H*D bytes: 0 = solid, else min(63, Chebyshev distance to the nearest solid voxel or to outside)
+//   vol.df    8 octant clearance fields of n1x*n1y*n1z*64 bytes each (4^3 bricks): 0 = solid, else min(63, side of the
+//             largest empty cube cornered at the voxel and extending towards the octant's signs)
 struct DevScene {
     VolumeView vol;
     const vrt_material* palette;
@@ -87,7 +88,7 @@ struct RowsParams {
 // launchers (vrt_device.hip)
 hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_t* occ1, uint64_t* occ2,
                                 uint64_t* occ3, hipStream_t s);
-hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, uint8_t* tmp, hipStream_t s);
+hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s);
 hipError_t launch_primary(const GeomParams& p, hipStream_t s);
 hipError_t launch_shade(const GeomParams& p, hipStream_t s);
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s);

@@ -48,8 +48,10 @@ struct VolumeView {
     const uint64_t* occ1;    // per 4^3 voxels, bit (x&3)|(y&3)<<2|(z&3)<<4
     const uint64_t* occ2;    // per 16^3
     const uint64_t* occ3;    // per 64^3
-    const uint8_t*  df;      // 64-byte bricks of 4^3 voxels (df_index): 0 = solid, else min(63, Chebyshev distance to the
-                             // nearest solid voxel)
+    const uint8_t*  df;      // 8 octant clearance fields, each in 64-byte bricks of 4^3 voxels (df_index): field o
+                             // (bit0: +x, bit1: +y, bit2: +z) holds per voxel 0 = solid, else min(63, side of the largest
+                             // empty cube that has this voxel as its corner and extends towards the octant's signs)
+    uint64_t        df_stride;  // bytes between octant fields
     int32_t W, H, D;
     int32_t n1x, n1y, n1z;
     int32_t n2x, n2y, n2z;
@@ -218,6 +220,16 @@ VRT_HD void finish(const DdaState& s, uint32_t material, uint32_t mask, uint32_t
     r.material = material; r.mask = mask; r.fetches = fetches; r.dbg0 = 0; r.dbg1 = 0;
 }
 
+// rint(x) as an int; NaN -> 0 (what v_cvt_i32_f32 does; spelled out for the host build)
+VRT_HD int steps_taken(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)rintf(x);
+#else
+    return x == x ? (int)rintf(x) : 0;
+#endif
+}
+
 // ---- wavefront votes (device: the 64 lanes of a gfx950 wave; host tests: a single lane) ------------------
 
 VRT_HD bool wave_all(bool p)
@@ -252,27 +264,32 @@ VRT_HD uint32_t wave_min_u6(uint32_t k)
 
 // ---- literal traversals ---------------------------------------------------------------------------------
 
-// DF (distance-field skip, wave-cooperative).  Profiling showed the per-iteration loops are bound by the
-// vector-memory pipe, not by arithmetic: one 64-lane byte gather per DDA iteration touches ~24 cache lines on
-// the bench frame and sits on the critical path of every iteration.  Here a second byte volume holds, per
-// empty voxel, the Chebyshev distance (capped at 63) to the nearest solid voxel; every DDA iteration moves at most one voxel along each axis, so from a voxel with clearance k the
-// next k-1 iterations cannot reach a solid voxel -- no memory test is needed for them (the walls of the volume
-// are handled by the per-axis distance to the wall the ray is heading for).
-// The lanes of a wave agree by ballot on the smallest clearance among them and run that many iterations of
-// pure ALU stepping (the same fp32 additions as the shader, hence bit-identical results), then look at
-// memory again.  Neighbouring rays have clearances within a voxel or two of each other, so the wave-wide
-// minimum costs little.  Finished lanes are masked off; the votes see live lanes only.
-template <class STATS>
-VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
+// DF (clearance-field skip, wave-cooperative).  Profiling showed the per-iteration loops are bound by the
+// vector-memory pipe and by instruction issue, not by arithmetic: one 64-lane byte gather per DDA iteration
+// touches ~24 cache lines on the bench frame and sits on the critical path of every iteration.  Here a set of
+// byte volumes holds, per empty voxel and per direction octant, the side k of the largest empty cube that has
+// the voxel as its corner and extends towards the octant's signs.  A ray only ever moves towards the signs of
+// its direction, at most one voxel per axis per DDA iteration, so its next k-1 iterations stay inside that cube:
+// no memory test is needed for them (unlike an isotropic distance field, the clearance of a ray LEAVING a
+// surface is large at once).  The lanes of a wave agree by ballot on the smallest clearance among them and run
+// that many iterations of pure ALU stepping -- the same fp32 additions as the shader, hence bit-identical
+// results -- then look at memory again.  Neighbouring rays have similar clearances, so the wave-wide minimum
+// costs little.  Finished lanes are masked off; the votes see live lanes only.
+template <bool SMALL, class STATS>
+VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
     dda_setup(v, start, dir, s);
     uint32_t mask = s.mask, material = 0, fetches = 0;
     bool done = false;
     uint32_t clear = 63u;
-    const bool small = (uint64_t)v.n1x * (uint64_t)v.n1y * (uint64_t)v.n1z * 64ull <= 0xFFFFFFFFull;   // wave-uniform
+    constexpr bool small = SMALL;                              // field below 4 GiB: 32-bit address arithmetic
+    // clearance field of the octant the ray travels into (an axis the ray does not move along can use either sign)
+    const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
+    const uint32_t octant32 = oct * (uint32_t)v.df_stride;
+    const size_t octant64 = (size_t)oct * (size_t)v.df_stride;
     const float kInf = u2f(0x7F800000u);
-    const float adx = fabsf(dir.x), ady = fabsf(dir.y), adz = fabsf(dir.z);
+    const float gx = s.dx < kInf ? fabsf(dir.x) : 0.0f, gy = s.dy < kInf ? fabsf(dir.y) : 0.0f, gz = s.dz < kInf ? fabsf(dir.z) : 0.0f;
     uint32_t i = 0;                                            // wave-uniform: every live lane has done i iterations
     uint32_t n_outer = 0, n_long = 0;
     for (;;) {
@@ -280,7 +297,7 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
         if (!done) {
             if (i >= maxSteps || oob(v, s.mx, s.my, s.mz)) { done = true; fetches = i; }
             else {
-                clear = small ? v.df[df_index32(v, s.mx, s.my, s.mz)] : v.df[df_index(v, s.mx, s.my, s.mz)];
+                clear = small ? v.df[octant32 + df_index32(v, s.mx, s.my, s.mz)] : v.df[octant64 + df_index(v, s.mx, s.my, s.mz)];
                 st_lookup(stats);
                 if (clear == 0u) {
                     material = small ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
@@ -328,15 +345,25 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
                 s.sdy = k1 ? s.sdy + s.dy : s.sdy;
                 s.sdz = k2 ? s.sdz + s.dz : s.sdz;
             }
-            // |dir| is 1/delta to within an ulp; axes that cannot step (dir = 0 or 1/dir overflowed) stay put
-            if (s.sx != 0 && s.dx < kInf) s.mx += s.sx * (int)rintf((s.sdx - ox) * adx);
-            if (s.sy != 0 && s.dy < kInf) s.my += s.sy * (int)rintf((s.sdy - oy) * ady);
-            if (s.sz != 0 && s.dz < kInf) s.mz += s.sz * (int)rintf((s.sdz - oz) * adz);
+            // |dir| is 1/delta to within an ulp; for axes that cannot step (dir = 0, or 1/dir overflowed) the
+            // multiplier is 0 and sideDist stays +inf: inf - inf = NaN converts to 0 steps
+            int nx = steps_taken((s.sdx - ox) * gx), ny = steps_taken((s.sdy - oy) * gy), nz = steps_taken((s.sdz - oz) * gz);
+            s.mx += s.sx < 0 ? -nx : nx;
+            s.my += s.sy < 0 ? -ny : ny;
+            s.mz += s.sz < 0 ? -nz : nz;
         }
         i += kw;
     }
     finish(s, material, mask, fetches, r);
     r.dbg0 = n_outer; r.dbg1 = n_long;
+}
+
+template <class STATS>
+VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
+{
+    // wave-uniform choice; the 64-bit variant is only reached by volumes whose bricked field is 4 GiB or more
+    if (8ull * v.df_stride <= 0xFFFFFFFFull) trace_df_impl<true>(v, start, dir, maxSteps, r, stats);
+    else trace_df_impl<false>(v, start, dir, maxSteps, r, stats);
 }
 
 // DENSE: one R8 fetch per iteration.  Straight-line body with a single exit (out of budget, out of bounds or
