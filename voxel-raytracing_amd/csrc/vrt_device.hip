@@ -323,9 +323,10 @@ __device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y
     int slot = b & 7, idx = b >> 3;
     int tx = idx % P.tiles_x, ty = (idx / P.tiles_x) * 8 + slot;
     if (ty >= P.tiles_y_local) return false;
-    int strip_local = ty / P.sh.tiles_per_strip, within = ty % P.sh.tiles_per_strip;
-    x0 = tx * 16;
-    y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + within * 16;
+    int tps = P.sh.strip_rows / P.tile;
+    int strip_local = ty / tps, within = ty % tps;
+    x0 = tx * P.tile;
+    y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + within * P.tile;
     return y0 < P.pc.screen_size[1];
 }
 
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
 template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
-    dim3 grid((unsigned)(p.chunk * 8)), block(256);
+    dim3 grid((unsigned)(p.chunk * 8)), block(p.tile == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1>), grid, block, lds, s, p);
     else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2>), grid, block, lds, s, p);
@@ -505,7 +506,7 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 {
     // one lane per hit pixel of the compacted list; sized for the worst case (every local pixel hit), surplus
     // workgroups leave at once
-    dim3 grid((unsigned)p.total_tiles), block(256);
+    dim3 grid((unsigned)(((size_t)p.total_tiles * p.tile * p.tile + 255) / 256)), block(256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     hipLaunchKernelGGL((k_shade<TRAV, OCC_LDS>), grid, block, lds, s, p);
     return hipGetLastError();
