@@ -58,7 +58,7 @@ void* th_create(const uint8_t* vox, int W, int H, int D)
                     int best = a[i];
                     for (int t = 1; t < best; t++) {
                         int q = pos + t * sg[axis];
-                        int val = (q < 0 || q >= dim) ? CAP + 1 : a[(long long)i + t * st];
+                        int val = (q < 0 || q >= dim) ? 0 : a[(long long)i + t * st];
                         int m = val > t ? val : t;
                         if (m < best) best = m;
                     }

@@ -427,10 +427,10 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     {
         uint32_t t = st->traversal;
         bool lds_mode = (t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP);
-        p.tile = (lds_mode || (st->flags & 8u)) ? 16 : 8;
+        p.tile_w = p.tile_h = (lds_mode || (st->flags & 8u)) ? 16 : 8;
     }
-    p.tiles_x = ceil_div(W, p.tile);
-    p.tiles_y_local = p.sh.n_local_strips * (p.sh.strip_rows / p.tile);
+    p.tiles_x = ceil_div(W, p.tile_w);
+    p.tiles_y_local = p.sh.n_local_strips * (p.sh.strip_rows / p.tile_h);
     p.total_tiles = p.tiles_x * p.tiles_y_local;
     p.chunk = p.tiles_x * ceil_div(p.tiles_y_local, 8);      // workgroups per XCD slot (tile rows are dealt round-robin)
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)

@@ -57,7 +57,7 @@ struct GeomParams {
     vrt_settings st;
     vrt_frame  fr;
     ShardMap   sh;
-    int32_t    tile;           // workgroup tile edge in pixels: 16 (4 waves of 8x8) or 8 (one wave)
+    int32_t    tile_w, tile_h; // workgroup tile in pixels: 16x16 (4 waves of 8x8) or 8x8 (one wave)
     int32_t    tiles_x, tiles_y_local, total_tiles, chunk;  // chunk = tiles per XCD slot
     uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)
     uint32_t*  hit_count;      // K1 -> K2: number of hit pixels (zeroed before K1)

@@ -50,7 +50,8 @@ struct VolumeView {
     const uint64_t* occ3;    // per 64^3
     const uint8_t*  df;      // 8 octant clearance fields, each in 64-byte bricks of 4^3 voxels (df_index): field o
                              // (bit0: +x, bit1: +y, bit2: +z) holds per voxel 0 = solid, else min(63, side of the largest
-                             // empty cube that has this voxel as its corner and extends towards the octant's signs)
+                             // empty cube that has this voxel as its corner and extends towards the octant's signs;
+                             // outside the volume counts as solid)
     uint64_t        df_stride;  // bytes between octant fields
     int32_t W, H, D;
     int32_t n1x, n1y, n1z;
@@ -252,7 +253,20 @@ VRT_HD bool wave_any(bool p)
 VRT_HD uint32_t wave_min_u6(uint32_t k)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t m = 0;
+    if (__ballot(true) == ~0ull) {
+        // all 64 lanes live (the common case): DPP min-scan, total in lane 63.  row_shr:1,2,4,8 fold each row of 16,
+        // row_bcast:15 / :31 fold the rows; lanes without a source keep `old` = 63, the identity.
+        uint32_t v = k;
+        uint32_t t;
+        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x111, 0xf, 0xf, false); v = v < t ? v : t;
+        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x112, 0xf, 0xf, false); v = v < t ? v : t;
+        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x114, 0xf, 0xf, false); v = v < t ? v : t;
+        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x118, 0xf, 0xf, false); v = v < t ? v : t;
+        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x142, 0xa, 0xf, false); v = v < t ? v : t;
+        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x143, 0xc, 0xf, false); v = v < t ? v : t;
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    }
+    uint32_t m = 0;                                           // partial waves: binary search over ballots
 #pragma unroll
     for (uint32_t bit = 32u; bit != 0u; bit >>= 1)
         if (__ballot(k < (m | bit)) == 0ull) m |= bit;
@@ -271,7 +285,7 @@ VRT_HD uint32_t wave_min_u6(uint32_t k)
 // the voxel as its corner and extends towards the octant's signs.  A ray only ever moves towards the signs of
 // its direction, at most one voxel per axis per DDA iteration, so its next k-1 iterations stay inside that cube:
 // no memory test is needed for them (unlike an isotropic distance field, the clearance of a ray LEAVING a
-// surface is large at once).  The lanes of a wave agree by ballot on the smallest clearance among them and run
+// surface is large at once).  Voxels outside the volume count as solid, which bounds a run at the walls.  The lanes of a wave agree by ballot on the smallest clearance among them and run
 // that many iterations of pure ALU stepping -- the same fp32 additions as the shader, hence bit-identical
 // results -- then look at memory again.  Neighbouring rays have similar clearances, so the wave-wide minimum
 // costs little.  Finished lanes are masked off; the votes see live lanes only.
@@ -308,17 +322,9 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             }
         }
         if (wave_all(done)) break;
-        // iterations this lane can take blind: fewer than its clearance to the nearest solid voxel and no more
-        // than it takes to reach the volume wall it is heading for (each iteration moves <= 1 voxel per axis)
-        uint32_t k = 63u;
-        if (!done) {
-            int nx = s.sx > 0 ? v.W - s.mx : (s.sx < 0 ? s.mx + 1 : 63);
-            int ny = s.sy > 0 ? v.H - s.my : (s.sy < 0 ? s.my + 1 : 63);
-            int nz = s.sz > 0 ? v.D - s.mz : (s.sz < 0 ? s.mz + 1 : 63);
-            int n = nx < ny ? nx : ny; n = n < nz ? n : nz;
-            k = (uint32_t)n < clear ? (uint32_t)n : clear;
-        }
-        uint32_t kw = wave_min_u6(k);                          // >= 1: live lanes stand on empty in-bounds voxels
+        // iterations the wave can take blind: the smallest clearance among its live lanes (the fields count the
+        // outside of the volume as solid, so a run cannot carry a lane further than one voxel past a wall)
+        uint32_t kw = wave_min_u6(done ? 63u : clear);         // >= 1: live lanes stand on empty in-bounds voxels
         uint32_t left = maxSteps - i;                          // i < maxSteps for every live lane
         kw = kw < left ? kw : left;
         st_jump(stats, kw > 4u ? 2 : 1);
