@@ -118,6 +118,24 @@ def test_step_budget_exhaustion(vrt, oracle, engine, trav):
         assert not bad, (max_steps, bad)
 
 
+def test_split_kernels_equal_megakernel(vrt, oracle, engine):
+    """K1 -> hit records -> K2 over the compacted hit list (VRT_FLAG_SPLIT_KERNELS) == the default megakernel."""
+    vol = vrt.synthetic.floating_cubes(64, seed=21, count=150)
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    res = (130, 90)
+    outs = []
+    for split in (False, True):
+        st = vrt.VoxelRenderSettings(targetResolution=res)
+        st.fsrSetttings.enable = False
+        st.traceSettings.splitKernels = split
+        push = camera_push(vrt, (64, 64, 64), res, frame=7)
+        got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
+        assert not compare_planes(got, exp, GB + DBG), split
+        outs.append(got)
+    assert not compare_planes(outs[0], outs[1], GB + DBG)
+
+
 def test_treehouse_1080p_properties(vrt, oracle, engine):
     """BASELINE config 2 at full size: size-independent properties + oracle parity on sampled rows."""
     vol = vrt.synthetic.treehouse(256, seed=2)
