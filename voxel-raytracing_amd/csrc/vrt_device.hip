@@ -681,14 +681,98 @@ __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
     reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
 }
 
+// LDS-tiled form for integral stepWidth: a workgroup owns 64x4 pixels; the guides of that tile plus a halo of
+// R = stepWidth pixels are fetched, decoded ONCE and parked in LDS as three float4 planes (48 B per pixel), so each
+// pixel's guides are read from HBM/L2 once per pass instead of once per tap that lands on it (9x), and the 8-bit
+// decodes are not repeated per tap.  Same arithmetic on the same decoded values as k_denoise.
+template <bool PHI_INF>
+__global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int R)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
+    const int RW = 64 + 2 * R, RH = 4 + 2 * R, NP = RW * RH;
+    float4* lc = lds_g; float4* ln = lds_g + NP; float4* lp = lds_g + 2 * NP;
+    const int x0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
+    const int y0 = strip_row(P.sh, P.extend, r0, P.H);        // rows of one block are consecutive frame rows (checked by the launcher)
+    if (y0 < 0) return;
+    for (int t = threadIdx.x; t < NP; t += 256) {
+        int lx = t % RW, ly = t / RW;
+        Guides g;
+        texel_guides(P, x0 - R + lx, y0 - R + ly, g);         // clamp-to-edge inside
+        lc[t] = make_float4(g.c[0], g.c[1], g.c[2], g.c[3]);
+        ln[t] = make_float4(g.n[0], g.n[1], g.n[2], g.n[3]);
+        lp[t] = make_float4(g.p[0], g.p[1], g.p[2], g.p[3]);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int px = x0 + lx, py = y0 + ly;
+    if (px >= P.W || py >= P.H) return;
+    if (strip_row(P.sh, P.extend, r0 + ly, P.H) != py) return;   // past the end of the strip / frame
+
+    const bool shipped = P.mode == VRT_DENOISE_AS_SHIPPED;
+    const int ntaps = shipped ? 3 : 9;
+    const float sw = P.step_width, sw2 = sw * sw;
+    const int c0 = (ly + R) * RW + (lx + R);
+    const float4 sc = lc[c0], sn = ln[c0], sp = lp[c0];
+    const float s_c[4] = {sc.x, sc.y, sc.z, sc.w}, s_n[4] = {sn.x, sn.y, sn.z, sn.w}, s_p[4] = {sp.x, sp.y, sp.z, sp.w};
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float total = 0.0f;
+    for (int i = 0; i < ntaps; i++) {
+        int tx, ty; float kern;
+        if (shipped) {
+            tx = i == 0 ? -1 : (i == 1 ? 1 : 0); ty = i == 2 ? 0 : -1;
+            kern = i == 1 ? kGauss0 : kGauss2;
+        } else {
+            tx = i % 3 - 1; ty = i / 3 - 1;
+            int r2 = tx * tx + ty * ty;
+            kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2);
+        }
+        const int ci = c0 + ty * R * RW + tx * R;
+        const float4 oc = lc[ci];
+        const float o_c[4] = {oc.x, oc.y, oc.z, oc.w};
+        float w = 1.0f;
+        if (!PHI_INF) {
+            const float4 op = lp[ci];
+            const float o_p[4] = {op.x, op.y, op.z, op.w};
+            float pw = edge_weight(dist2_4(s_p, o_p), P.phi_pos);
+            float cw = 1.0f, nw = 1.0f;
+            if (pw != 0.0f) {
+                const float4 on = ln[ci];
+                const float o_n[4] = {on.x, on.y, on.z, on.w};
+                cw = edge_weight(dist2_4(s_c, o_c), P.phi_color);
+                float dn = dist2_4(s_n, o_n);
+                nw = dn == 0.0f ? 1.0f : edge_weight(fmaxf(dn / sw2, 0.0f), P.phi_normal);
+            }
+            w = (cw * nw) * pw;
+        }
+        for (int k = 0; k < 4; k++) sum[k] += (o_c[k] * w) * kern;
+        total += w * kern;
+    }
+    uchar4 out;
+    out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
+    out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
+    reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
+}
+
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
 {
-    int rows = p.sh.n_local_strips * (p.sh.strip_rows + 2 * p.extend);
+    int per = p.sh.strip_rows + 2 * p.extend;
+    int rows = p.sh.n_local_strips * per;
     dim3 grid((unsigned)((p.W + 63) / 64), (unsigned)((rows + 3) / 4)), block(256);
     // phi = +inf in all three channels <=> pass 0 (denoiser_stage.cpp:148-150)
     bool inf = __builtin_isinf(p.phi_color) && __builtin_isinf(p.phi_normal) && __builtin_isinf(p.phi_pos);
-    if (inf) hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, s, p);
-    else     hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, s, p);
+    // LDS tiling needs an integral tap offset, a halo that fits (<= 5 px: 74 x 14 px x 48 B = 48.6 KiB) and blocks of
+    // 4 consecutive frame rows (single strip, or strips whose extended height is a multiple of 4)
+    float sw = p.step_width;
+    int R = (int)sw;
+    bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
+    if (tiled) {
+        size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * 48;
+        if (inf) hipLaunchKernelGGL(k_denoise_lds<true>, grid, block, lds, s, p, R);
+        else     hipLaunchKernelGGL(k_denoise_lds<false>, grid, block, lds, s, p, R);
+    } else {
+        if (inf) hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, s, p);
+        else     hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, s, p);
+    }
     return hipGetLastError();
 }
 
