@@ -31,3 +31,6 @@ print("active waves every 10us:", active)
 print("waves started every 10us:", np.histogram(start, bins=edges)[0].tolist())
 late = dur > np.percentile(dur, 99)
 print("99th pct dur", np.percentile(dur, 99), "start of slowest 1%: mean", start[late].mean(), "end", end[late].mean())
+rows = dur.mean(axis=1)
+print("mean wave duration by 8-px row group (every 8th):", [round(float(x), 1) for x in rows[::8]])
+print("mean start time by row group (every 8th):", [round(float(x), 1) for x in start.mean(axis=1)[::8]])

@@ -323,6 +323,9 @@ __device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y
     int slot = b & 7, idx = b >> 3;
     int tx = idx % P.tiles_x, ty = (idx / P.tiles_x) * 8 + slot;
     if (ty >= P.tiles_y_local) return false;
+    // bottom rows first: the rows dispatched last only have the drain of the machine to hide in, and the top of a
+    // frame is where the cheap sky-only tiles usually are
+    ty = P.tiles_y_local - 1 - ty;
     int tps = P.sh.strip_rows / P.tile_h;
     int strip_local = ty / tps, within = ty % tps;
     x0 = tx * P.tile_w;
