@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=256)
-    ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP", "DF"])
+    ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -96,6 +96,10 @@ void th_trace(void* p, int trav, int n, const float* starts, const float* dirs, 
             total.retrace += st.retrace; total.lookups += st.lookups;
         } else if (trav == VRT_TRAVERSAL_BITMASK) {
             trace_literal<VRT_TRAVERSAL_BITMASK>(h->v, h->v.occ2, s, d, maxSteps, r);
+        } else if (trav == VRT_TRAVERSAL_DFJ) {
+            TraceStats st;
+            trace_dfj(h->v, s, d, maxSteps, r, st);
+            total.jumps1 += st.jumps1; total.jumps3 += st.jumps3; total.lookups += st.lookups; total.retrace += st.retrace;
         } else if (trav == VRT_TRAVERSAL_DF) {
             TraceStats st;
             trace_df(h->v, s, d, maxSteps, r, st);

@@ -32,7 +32,7 @@ def _render_both(vrt, oracle, engine, gs, osn, settings, push, shard=None):
     return got, exp
 
 
-@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF"])
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
 @pytest.mark.parametrize("mode", ["primary_only", "shadow_only", "default_ao_shadow_bounce"])
 def test_geometry_bit_exact_floating_cubes(vrt, oracle, engine, trav, mode):
     vol = vrt.synthetic.floating_cubes(64, seed=1, count=120)
@@ -48,7 +48,7 @@ def test_geometry_bit_exact_floating_cubes(vrt, oracle, engine, trav, mode):
         st.occlusionSettings.numSamples = 4
     push = camera_push(vrt, (64, 64, 64), res, frame=3)
     got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
-    names = GB + DBG if trav != "JUMP" else GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
+    names = GB + DBG if trav not in ("JUMP", "DFJ") else GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
     bad = compare_planes(got, exp, names)
     assert not bad, bad
     assert (exp["hit_id"] != 0).mean() > 0.2 and (exp["hit_id"] == 0).mean() > 0.05     # both cases exercised
@@ -56,7 +56,7 @@ def test_geometry_bit_exact_floating_cubes(vrt, oracle, engine, trav, mode):
         assert (exp["rays_total"] > 6).any()                                             # some metallic bounces
 
 
-@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF"])
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
 def test_geometry_bit_exact_odd_sizes_and_views(vrt, oracle, engine, trav):
     # non-multiple-of-4 volume, ragged frame (not a multiple of the 16x16 tile), cameras inside / above / tilted
     rng = np.random.default_rng(12)
@@ -73,12 +73,12 @@ def test_geometry_bit_exact_odd_sizes_and_views(vrt, oracle, engine, trav):
         st.traceSettings.maxReflections = 3
         push = camera_push(vrt, (51, 22, 37), res, pos=pos, yaw=yaw, pitch=pitch, frame=33, jitter=(0.25, -0.4))
         got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
-        names = GB + DBG if trav != "JUMP" else GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
+        names = GB + DBG if trav not in ("JUMP", "DFJ") else GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
         bad = compare_planes(got, exp, names)
         assert not bad, (pos, bad)
 
 
-@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF"])
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
 def test_exact_ties_and_axis_parallel_rays(vrt, oracle, engine, trav):
     # camera on a lattice point looking down an axis: centre rays are axis-parallel (1/0 = inf deltas),
     # diagonal pixels hit exact sideDist ties (multi-axis masks, diagonal normals)
@@ -102,7 +102,7 @@ def test_exact_ties_and_axis_parallel_rays(vrt, oracle, engine, trav):
     assert np.isin(exp["hit_mask"], [3, 5, 6, 7]).any()          # tie masks occurred
 
 
-@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF"])
+@pytest.mark.parametrize("trav", ["DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
 def test_step_budget_exhaustion(vrt, oracle, engine, trav):
     # a wall that most rays reach only after more DDA iterations than max_steps allows
     vol = np.zeros((200, 24, 24), np.uint8); vol[190:, :, :] = 3
@@ -146,7 +146,7 @@ def test_treehouse_1080p_properties(vrt, oracle, engine):
     pos, yaw, pitch = vrt.synthetic.default_camera_for(256, 256, 256)
     push = camera_push(vrt, (256, 256, 256), res, pos=pos, yaw=yaw, pitch=pitch)
     outs = {}
-    for trav in ("DENSE", "BITMASK", "JUMP", "DF"):
+    for trav in ("DENSE", "BITMASK", "JUMP", "DF", "DFJ"):
         st = vrt.VoxelRenderSettings.primary_only(res, getattr(vrt, "TRAVERSAL_" + trav))
         stage = vrt.GeometryStage(engine, st, gs, debug_planes=True)
         gb = stage.record(push)
@@ -154,8 +154,8 @@ def test_treehouse_1080p_properties(vrt, oracle, engine):
         outs[trav] = gb.numpy()
     o = outs["DENSE"]
     # traversal modes agree bit-for-bit at full size
-    for trav in ("BITMASK", "JUMP", "DF"):
-        names = GB + ["color_f", "hit_id", "hit_voxel", "hit_mask"] + (["steps_primary"] if trav != "JUMP" else [])
+    for trav in ("BITMASK", "JUMP", "DF", "DFJ"):
+        names = GB + ["color_f", "hit_id", "hit_voxel", "hit_mask"] + (["steps_primary"] if trav not in ("JUMP", "DFJ") else [])
         assert not compare_planes(outs[trav], o, names), trav
     # the hit cell really holds the reported id; misses report 0 everywhere
     hit = o["hit_id"] != 0

@@ -78,12 +78,12 @@ def test_strategies_match_oracle_random_rays(th, oracle, seed, dims, fill):
     starts, dirs = _rays(rng, 6000, dims)
     for max_steps in (512, 64, 37):
         exp = oracle_trace(oracle, osn, starts, dirs, max_steps)
-        for trav, name in ((1, "DENSE"), (2, "BITMASK"), (4, "DF"), (3, "JUMP")):
+        for trav, name in ((1, "DENSE"), (2, "BITMASK"), (4, "DF"), (3, "JUMP"), (5, "DFJ")):
             got, stats = trace(th, h, trav, starts, dirs, max_steps)
-            cols = slice(0, 12) if trav != 3 else slice(0, 11)          # JUMP's fetch count is an upper bound
+            cols = slice(0, 12) if trav not in (3, 5) else slice(0, 11)  # JUMP / DFJ fetch counts are upper bounds
             bad = np.flatnonzero((got[:, cols] != exp[:, cols]).any(axis=1))
             assert bad.size == 0, (name, max_steps, bad[:5], got[bad[:3]], exp[bad[:3]], starts[bad[:3]], dirs[bad[:3]])
-            if trav == 3:
+            if trav in (3, 5):
                 assert (got[:, 11] >= exp[:, 11]).all()
     th.th_destroy(h)
 

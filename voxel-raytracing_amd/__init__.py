@@ -3,7 +3,7 @@ ectucker1/voxel-raytracing (shader/voxel_volume.frag + shader/denoiser.frag), be
 .vox-load -> render-to-RGBA call surface.  HIP kernels + C-ABI: csrc/ (libvrt_hip.so, include/vrt.h);
 this package is the Python host side (ctypes) mirroring the reference's objects."""
 from . import _capi
-from ._capi import (TRAVERSAL_AUTO, TRAVERSAL_DENSE, TRAVERSAL_BITMASK, TRAVERSAL_JUMP, TRAVERSAL_DF,
+from ._capi import (TRAVERSAL_AUTO, TRAVERSAL_DENSE, TRAVERSAL_BITMASK, TRAVERSAL_JUMP, TRAVERSAL_DF, TRAVERSAL_DFJ,
                     DENOISE_CANONICAL, DENOISE_AS_SHIPPED, VrtError, lib)
 from .host import (AmbientOcclusionSettings, CameraController, DenoiserSettings, DenoiserStage, Engine,
                    FsrScaling, FsrSettings, GeometryBuffer, GeometryStage, LightSettings, TraceSettings,

@@ -411,7 +411,7 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     if (push->volume_bounds[0] != (uint32_t)s->d.vol.W || push->volume_bounds[1] != (uint32_t)s->d.vol.H || push->volume_bounds[2] != (uint32_t)s->d.vol.D)
         return fail(VRT_ERR_INVALID, "vrt_render_geometry: push.volume_bounds must equal the scene dimensions (voxel_renderer.cpp:74)");
     if (st->max_bounces > VRT_MAX_BOUNCES) return fail(VRT_ERR_INVALID, "vrt_render_geometry: max_bounces > VRT_MAX_BOUNCES");
-    if (st->traversal > VRT_TRAVERSAL_DF) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
+    if (st->traversal > VRT_TRAVERSAL_DFJ) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
     if (st->traversal == VRT_TRAVERSAL_DENSE && (uint64_t)s->d.vol.W * (uint64_t)s->d.vol.H * (uint64_t)s->d.vol.D > 0xFFFFFFFFull)
         return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: VRT_TRAVERSAL_DENSE indexes voxels in 32 bits (volumes below 4 GiB)");
     HIPCHK(hipSetDevice(c->device));

@@ -242,7 +242,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
             f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
             RayInt r;
             // AO rays have a 64-iteration budget: too short for jumps to pay, and budget ties would force re-traces
-            trace_int<(TRAV == VRT_TRAVERSAL_JUMP ? VRT_TRAVERSAL_DF : TRAV)>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);
+            trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV)>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);
             c.fetches += r.fetches; c.rays++;
             if (r.material != 0) ambient += sample_frac;
         }
@@ -519,7 +519,7 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 
 static int effective_traversal(int t)
 {
-    if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP) return t;
+    if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP || t == VRT_TRAVERSAL_DFJ) return t;
     return VRT_TRAVERSAL_DF;        // AUTO / DF
 }
 
@@ -528,6 +528,7 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s)
     int t = effective_traversal((int)p.st.traversal);
     if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_primary_t<VRT_TRAVERSAL_DF, false>(p, s);
+    if (t == VRT_TRAVERSAL_DFJ) return launch_primary_t<VRT_TRAVERSAL_DFJ, false>(p, s);
     if (t == VRT_TRAVERSAL_BITMASK) return p.occ_in_lds ? launch_primary_t<VRT_TRAVERSAL_BITMASK, true>(p, s) : launch_primary_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
     return p.occ_in_lds ? launch_primary_t<VRT_TRAVERSAL_JUMP, true>(p, s) : launch_primary_t<VRT_TRAVERSAL_JUMP, false>(p, s);
 }
@@ -537,6 +538,7 @@ hipError_t launch_shade(const GeomParams& p, hipStream_t s)
     int t = effective_traversal((int)p.st.traversal);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_shade_t<VRT_TRAVERSAL_DF, false>(p, s);
+    if (t == VRT_TRAVERSAL_DFJ) return launch_shade_t<VRT_TRAVERSAL_DFJ, false>(p, s);
     if (t == VRT_TRAVERSAL_BITMASK) return p.occ_in_lds ? launch_shade_t<VRT_TRAVERSAL_BITMASK, true>(p, s) : launch_shade_t<VRT_TRAVERSAL_BITMASK, false>(p, s);
     return p.occ_in_lds ? launch_shade_t<VRT_TRAVERSAL_JUMP, true>(p, s) : launch_shade_t<VRT_TRAVERSAL_JUMP, false>(p, s);
 }

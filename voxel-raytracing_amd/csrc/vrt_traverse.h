@@ -38,6 +38,7 @@
 #define VRT_TRAVERSAL_BITMASK 2
 #define VRT_TRAVERSAL_JUMP 3
 #define VRT_TRAVERSAL_DF 4
+#define VRT_TRAVERSAL_DFJ 5
 #endif
 
 namespace vrt {
@@ -613,6 +614,99 @@ VRT_HD void trace_jump(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
     finish(s, material, mask, hit ? it_up + 1u : it_up, r);
 }
 
+// DFJ: DF with the long runs done in closed form.  A lane whose clearance is >= kJumpMin does not walk its run: the
+// cube its clearance guarantees empty is exactly the kind of region trace_jump() leaves in one step, so it jumps to the
+// cube's exit (or as far as its sideDist binades allow) with the integer closed form above, independently of the other
+// lanes.  Lanes with small clearances walk wave-cooperative runs as in DF.  Iteration counts become bounds
+// (lo <= iterations <= lo + slack); hits that straddle the budget are re-traced literally, as in JUMP.
+template <class STATS>
+VRT_HD void trace_dfj(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
+{
+    constexpr uint32_t kJumpMin = 12u;
+    DdaState s;
+    dda_setup(v, start, dir, s);
+    uint32_t mask = s.mask, material = 0;
+    bool done = false, hit = false;
+    uint32_t clear = 63u;
+    const bool small = 8ull * v.df_stride <= 0xFFFFFFFFull;
+    const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
+    const size_t octant = (size_t)oct * (size_t)v.df_stride;
+    const float kInf = u2f(0x7F800000u);
+    const float gx = s.dx < kInf ? fabsf(dir.x) : 0.0f, gy = s.dy < kInf ? fabsf(dir.y) : 0.0f, gz = s.dz < kInf ? fabsf(dir.z) : 0.0f;
+    uint32_t lo = 0, slack = 0;                                // lo <= DDA iterations done so far <= lo + slack
+    for (;;) {
+        if (!done) {
+            if (lo >= maxSteps || oob(v, s.mx, s.my, s.mz)) done = true;       // certainly out of budget, or out of the volume
+            else {
+                clear = small ? v.df[(uint32_t)octant + df_index32(v, s.mx, s.my, s.mz)] : v.df[octant + df_index(v, s.mx, s.my, s.mz)];
+                st_lookup(stats);
+                if (clear == 0u) { hit = true; done = true; }
+            }
+        }
+        if (wave_all(done)) break;
+        const bool jumper = !done && clear >= kJumpMin;
+        if (jumper) {
+            JumpAxis ax, ay, az;
+            jump_axis_prepare(s.sdx, s.dx, s.sx, (int)clear, ax);
+            jump_axis_prepare(s.sdy, s.dy, s.sy, (int)clear, ay);
+            jump_axis_prepare(s.sdz, s.dz, s.sz, (int)clear, az);
+            uint32_t Tstar = ax.T < ay.T ? ax.T : ay.T;
+            Tstar = Tstar < az.T ? Tstar : az.T;
+            if (Tstar == 0xFFFFFFFFu) { done = true; }        // direction (0,0,0): the literal loop spins to its budget -> miss
+            else {
+                bool l0, l1, l2;
+                int c0 = jump_axis_apply(ax, Tstar, s.dx, s.sdx, l0);
+                int c1 = jump_axis_apply(ay, Tstar, s.dy, s.sdy, l1);
+                int c2 = jump_axis_apply(az, Tstar, s.dz, s.sdz, l2);
+                s.mx += c0 * s.sx; s.my += c1 * s.sy; s.mz += c2 * s.sz;
+                mask = (uint32_t)l0 | ((uint32_t)l1 << 1) | ((uint32_t)l2 << 2);
+                int cm = c0 > c1 ? c0 : c1; cm = cm > c2 ? cm : c2;
+                lo += (uint32_t)cm; slack += (uint32_t)(c0 + c1 + c2 - cm);
+                st_jump(stats, 3);
+            }
+        }
+        const bool walker = !done && !jumper;
+        if (wave_any(walker)) {
+            uint32_t kw = wave_min_u6(walker ? clear : 63u);
+            st_jump(stats, 1);
+            if (walker) {
+                const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
+                for (uint32_t j = 1; j < kw; j++) {
+                    uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+                    uint32_t mn = umin3(bx, by, bz);
+                    s.sdx = bx == mn ? s.sdx + s.dx : s.sdx;
+                    s.sdy = by == mn ? s.sdy + s.dy : s.sdy;
+                    s.sdz = bz == mn ? s.sdz + s.dz : s.sdz;
+                }
+                {
+                    uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+                    uint32_t mn = umin3(bx, by, bz);
+                    bool k0 = bx == mn, k1 = by == mn, k2 = bz == mn;
+                    mask = (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2);
+                    s.sdx = k0 ? s.sdx + s.dx : s.sdx;
+                    s.sdy = k1 ? s.sdy + s.dy : s.sdy;
+                    s.sdz = k2 ? s.sdz + s.dz : s.sdz;
+                }
+                int nx = steps_taken((s.sdx - ox) * gx), ny = steps_taken((s.sdy - oy) * gy), nz = steps_taken((s.sdz - oz) * gz);
+                s.mx += s.sx < 0 ? -nx : nx;
+                s.my += s.sy < 0 ? -ny : ny;
+                s.mz += s.sz < 0 ? -nz : nz;
+                lo += kw;
+            }
+        }
+    }
+    if (hit) {
+        if (lo + slack < maxSteps) material = voxel_at(v, s.mx, s.my, s.mz);   // the literal loop reaches this fetch within its budget
+        else if (lo >= maxSteps) hit = false;                                   // certainly exhausted before it
+        else {
+            st_retrace(stats);
+            trace_df(v, start, dir, maxSteps, r, stats);                         // ambiguous (ties near the budget): decide literally
+            return;
+        }
+    }
+    finish(s, material, mask, hit ? lo + slack + 1u : lo + slack, r);
+}
+
 // Dispatcher used by the kernels.
 template <int TRAV, class OP>
 VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
@@ -624,6 +718,9 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
     } else if (TRAV == VRT_TRAVERSAL_DF) {
         NoStats ns;
         trace_df(v, start, dir, maxSteps, r, ns);
+    } else if (TRAV == VRT_TRAVERSAL_DFJ) {
+        NoStats ns;
+        trace_dfj(v, start, dir, maxSteps, r, ns);
     } else {
         trace_literal<TRAV>(v, o2, start, dir, maxSteps, r);
     }
