@@ -158,6 +158,18 @@ void vrt_host_free(void* p);
 int  vrt_scene_set_sky(vrt_ctx* ctx, vrt_scene* sc, const float* rgba, uint32_t w, uint32_t h);
 /* Texture2D(blue_noise_rgba.png, RGBA8_UNORM) (voxel_renderer.cpp:22).  Default: 1x1 mid-grey. */
 int  vrt_scene_set_blue_noise(vrt_ctx* ctx, vrt_scene* sc, const uint8_t* rgba8, uint32_t w, uint32_t h);
+/* Texture2D(engine, filepath, 4, format) (source/engine/resource/texture_2d.cpp:22-44): decode the file on the host
+ * (Radiance .hdr -> linear float RGBA like stbi_loadf, PNG -> RGBA8 like stbi_load) and upload it.  An 8-bit image given
+ * as sky is converted c/255; a float image given as noise is rejected.  Failure: "Could not load image <path>". */
+int  vrt_scene_set_sky_file(vrt_ctx* ctx, vrt_scene* sc, const char* path);
+int  vrt_scene_set_blue_noise_file(vrt_ctx* ctx, vrt_scene* sc, const char* path);
+/* The decoders alone (host only).  *pixels: float RGBA (is_hdr = 1) or RGBA8 (is_hdr = 0), release with vrt_host_free. */
+int  vrt_image_load(const char* path, int* is_hdr, uint32_t* w, uint32_t* h, void** pixels);
+/* Writers for rendered frames (host memory): 8-bit PNG / binary PPM from RGBA8, PFM from float RGB(A) with the given
+ * stride in floats (3 for color_f, 4 for position). */
+int  vrt_image_write_png(const char* path, const uint8_t* rgba8, uint32_t w, uint32_t h);
+int  vrt_image_write_ppm(const char* path, const uint8_t* rgba8, uint32_t w, uint32_t h);
+int  vrt_image_write_pfm(const char* path, const float* pixels, uint32_t w, uint32_t h, uint32_t stride_floats);
 /* VoxelScene::width/height/depth (voxel_scene.hpp:21). */
 int  vrt_scene_info(const vrt_scene* sc, uint32_t dims[3]);
 /* Copy the dense volume / palette back to the host (tests, oracle comparison). */

@@ -4,6 +4,8 @@ Bar: every G-buffer plane, every debug plane and the fp32 pre-quantisation colou
 (the numeric spec pins atan/asin/exp/normalize and forbids FMA contraction, so no tolerance is needed);
 hit voxel ids / cells / masks are integers and trivially so.  Tolerance stated per test: 0 ulp.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -206,6 +208,33 @@ def test_vox_file_load_matches_from_dense(vrt, oracle, engine, tmp_path):
         vrt.VoxelScene(engine, str(bad))
     with pytest.raises(RuntimeError, match="does not contain an instance"):
         vrt.VoxelScene.from_memory(engine, open(os.path.join(gold, "vox_err_no_instance.vox"), "rb").read())
+
+
+def test_sky_and_noise_from_files(vrt, oracle, engine, tmp_path):
+    """Texture2D path: sky from a Radiance .hdr and blue noise from a PNG, decoded by the library."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_image_io import _rgbe_encode, _hdr_file, _expected_float
+    from PIL import Image
+    rng = np.random.default_rng(8)
+    rgbe = _rgbe_encode(rng.random((16, 32, 3)) * 4.0)
+    (tmp_path / "sky.hdr").write_bytes(_hdr_file(rgbe, True))
+    noise = rng.integers(0, 256, (64, 64, 4), dtype=np.uint8)
+    Image.fromarray(noise, "RGBA").save(tmp_path / "noise.png")
+    vol = vrt.synthetic.floating_cubes(32, seed=5, count=40)
+    pal = metallic_palette(vrt)
+    sc = vrt.VoxelScene.from_dense(engine, vol, pal)
+    sc.set_sky(str(tmp_path / "sky.hdr")); sc.set_blue_noise(str(tmp_path / "noise.png"))
+    osn = oracle.OracleScene(vol, pal, sky=_expected_float(rgbe), noise=noise)
+    res = (64, 48)
+    st = vrt.VoxelRenderSettings(targetResolution=res); st.fsrSetttings.enable = False
+    push = camera_push(vrt, (32, 32, 32), res, frame=2)
+    stage = vrt.GeometryStage(engine, st, sc, debug_planes=True)
+    gb = stage.record(push); engine.synchronize()
+    exp = oracle.render(osn, push, oracle.params_from(st.to_c()), nthreads=4)
+    assert not compare_planes(gb.numpy(), exp, GB + DBG)
+    with pytest.raises(RuntimeError, match="Could not load image"):
+        sc.set_sky(str(tmp_path / "nope.hdr"))
 
 
 def test_argument_validation(vrt, engine):

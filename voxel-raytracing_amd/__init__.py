@@ -7,7 +7,8 @@ from ._capi import (TRAVERSAL_AUTO, TRAVERSAL_DENSE, TRAVERSAL_BITMASK, TRAVERSA
                     DENOISE_CANONICAL, DENOISE_AS_SHIPPED, VrtError, lib)
 from .host import (AmbientOcclusionSettings, CameraController, DenoiserSettings, DenoiserStage, Engine,
                    FsrScaling, FsrSettings, GeometryBuffer, GeometryStage, LightSettings, TraceSettings,
-                   VoxelRenderSettings, VoxelRenderer, VoxelScene, make_push, make_shard, vox_flatten_host)
+                   VoxelRenderSettings, VoxelRenderer, VoxelScene, load_image, make_push, make_shard, vox_flatten_host,
+                   write_image)
 from . import synthetic
 from . import distributed
 

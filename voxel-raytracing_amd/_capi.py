@@ -79,6 +79,12 @@ SYMBOLS = {
     "vrt_host_free": (None, [_P]),
     "vrt_scene_set_sky": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32]),
     "vrt_scene_set_blue_noise": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32]),
+    "vrt_scene_set_sky_file": (C.c_int, [_P, _P, C.c_char_p]),
+    "vrt_scene_set_blue_noise_file": (C.c_int, [_P, _P, C.c_char_p]),
+    "vrt_image_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(_P)]),
+    "vrt_image_write_png": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+    "vrt_image_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+    "vrt_image_write_pfm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vrt_scene_info": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "vrt_scene_download": (C.c_int, [_P, _P, _P, C.POINTER(Material)]),
     "vrt_scene_free": (None, [_P, _P]),

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "image_io.h"
 #include "vox_reader.h"
 #include "vrt_internal.h"
 
@@ -318,6 +319,65 @@ int vrt_scene_load_vox_file(vrt_ctx* c, const char* path, vrt_scene** out)
     fclose(f);
     if (buf.empty()) return fail(VRT_ERR_IO, "Failed to read voxel scene");
     return vrt_scene_load_vox_mem(c, buf.data(), buf.size(), out);
+}
+
+int vrt_image_load(const char* path, int* is_hdr, uint32_t* w, uint32_t* h, void** pixels)
+{
+    if (!path || !w || !h || !pixels) return fail(VRT_ERR_INVALID, "vrt_image_load: NULL argument");
+    LoadedImage img; std::string err;
+    int rc = image_load(path, img, err);
+    if (rc != VRT_OK) return fail(rc, err);
+    size_t bytes = img.is_hdr ? img.f32.size() * sizeof(float) : img.u8.size();
+    void* p = malloc(bytes ? bytes : 1);
+    if (!p) return fail(VRT_ERR_INVALID, "out of host memory");
+    memcpy(p, img.is_hdr ? (const void*)img.f32.data() : (const void*)img.u8.data(), bytes);
+    *pixels = p; *w = img.w; *h = img.h;
+    if (is_hdr) *is_hdr = img.is_hdr ? 1 : 0;
+    return VRT_OK;
+}
+
+int vrt_scene_set_sky_file(vrt_ctx* c, vrt_scene* s, const char* path)
+{
+    if (!c || !s || !path) return fail(VRT_ERR_INVALID, "vrt_scene_set_sky_file: NULL argument");
+    LoadedImage img; std::string err;
+    int rc = image_load(path, img, err);
+    if (rc != VRT_OK) return fail(rc, err);
+    if (!img.is_hdr) {                                        // 8-bit image as sky: c/255 per channel
+        img.f32.resize(img.u8.size());
+        for (size_t i = 0; i < img.u8.size(); i++) img.f32[i] = (float)img.u8[i] / 255.0f;
+    }
+    return vrt_scene_set_sky(c, s, img.f32.data(), img.w, img.h);
+}
+
+int vrt_scene_set_blue_noise_file(vrt_ctx* c, vrt_scene* s, const char* path)
+{
+    if (!c || !s || !path) return fail(VRT_ERR_INVALID, "vrt_scene_set_blue_noise_file: NULL argument");
+    LoadedImage img; std::string err;
+    int rc = image_load(path, img, err);
+    if (rc != VRT_OK) return fail(rc, err);
+    if (img.is_hdr) return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_set_blue_noise_file: the noise texture is RGBA8_UNORM, got a float image");
+    return vrt_scene_set_blue_noise(c, s, img.u8.data(), img.w, img.h);
+}
+
+int vrt_image_write_png(const char* path, const uint8_t* rgba8, uint32_t w, uint32_t h)
+{
+    if (!path || !rgba8 || !w || !h) return fail(VRT_ERR_INVALID, "vrt_image_write_png: bad argument");
+    std::string err; int rc = image_write_png(path, rgba8, w, h, err);
+    return rc == VRT_OK ? rc : fail(rc, err);
+}
+
+int vrt_image_write_ppm(const char* path, const uint8_t* rgba8, uint32_t w, uint32_t h)
+{
+    if (!path || !rgba8 || !w || !h) return fail(VRT_ERR_INVALID, "vrt_image_write_ppm: bad argument");
+    std::string err; int rc = image_write_ppm(path, rgba8, w, h, err);
+    return rc == VRT_OK ? rc : fail(rc, err);
+}
+
+int vrt_image_write_pfm(const char* path, const float* pixels, uint32_t w, uint32_t h, uint32_t stride_floats)
+{
+    if (!path || !pixels || !w || !h || stride_floats < 3) return fail(VRT_ERR_INVALID, "vrt_image_write_pfm: bad argument");
+    std::string err; int rc = image_write_pfm(path, pixels, w, h, stride_floats, err);
+    return rc == VRT_OK ? rc : fail(rc, err);
 }
 
 int vrt_scene_info(const vrt_scene* s, uint32_t dims[3])

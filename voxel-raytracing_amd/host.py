@@ -16,6 +16,7 @@ torch is used only for device buffers and the stream; every computation goes thr
 import ctypes as C
 import enum
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -308,12 +309,28 @@ class VoxelScene:
         check(lib().vrt_scene_info(self._h, d))
         self.width, self.height, self.depth = int(d[0]), int(d[1]), int(d[2])
 
-    def set_sky(self, rgba: np.ndarray):
+    def set_sky(self, rgba):
+        if isinstance(rgba, (str, bytes, os.PathLike)):       # Texture2D(skyboxPath, 4, RGBA32F): decode on the host
+            rc = lib().vrt_scene_set_sky_file(self.engine.ctx, self._h, os.fsencode(rgba))
+            if rc != _capi.VRT_OK:
+                raise RuntimeError(lib().vrt_last_error().decode())      # "Could not load image <path>" (texture_2d.cpp:42)
+            return
+        self._set_sky_array(rgba)
+
+    def _set_sky_array(self, rgba: np.ndarray):
         a = np.ascontiguousarray(rgba, dtype=np.float32)
         assert a.ndim == 3 and a.shape[2] == 4
         check(lib().vrt_scene_set_sky(self.engine.ctx, self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
 
-    def set_blue_noise(self, rgba8: np.ndarray):
+    def set_blue_noise(self, rgba8):
+        if isinstance(rgba8, (str, bytes, os.PathLike)):      # Texture2D("blue_noise_rgba.png", 4, RGBA8_UNORM)
+            rc = lib().vrt_scene_set_blue_noise_file(self.engine.ctx, self._h, os.fsencode(rgba8))
+            if rc != _capi.VRT_OK:
+                raise RuntimeError(lib().vrt_last_error().decode())
+            return
+        self._set_noise_array(rgba8)
+
+    def _set_noise_array(self, rgba8: np.ndarray):
         a = np.ascontiguousarray(rgba8, dtype=np.uint8)
         assert a.ndim == 3 and a.shape[2] == 4
         check(lib().vrt_scene_set_blue_noise(self.engine.ctx, self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
@@ -340,6 +357,34 @@ class VoxelScene:
             self.destroy()
         except Exception:
             pass
+
+
+def load_image(path):
+    """Host-side decoder behind Texture2D (Radiance .hdr -> float32 RGBA, PNG -> uint8 RGBA)."""
+    hdr, w, h, px = C.c_int(), C.c_uint32(), C.c_uint32(), C.c_void_p()
+    rc = lib().vrt_image_load(os.fsencode(path), C.byref(hdr), C.byref(w), C.byref(h), C.byref(px))
+    if rc != _capi.VRT_OK:
+        raise RuntimeError(lib().vrt_last_error().decode())
+    n = w.value * h.value * 4
+    if hdr.value:
+        a = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), shape=(n,)).copy().reshape(h.value, w.value, 4)
+    else:
+        a = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), shape=(n,)).copy().reshape(h.value, w.value, 4)
+    lib().vrt_host_free(px)
+    return a
+
+
+def write_image(path, array):
+    """PNG / PPM from uint8 RGBA (H,W,4); PFM from float32 (H,W,3|4)."""
+    a = np.ascontiguousarray(array)
+    p = os.fsencode(path)
+    H, W = a.shape[:2]
+    if a.dtype == np.uint8:
+        fn = lib().vrt_image_write_ppm if str(path).lower().endswith(".ppm") else lib().vrt_image_write_png
+        check(fn(p, a.ctypes.data_as(C.c_void_p), W, H))
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        check(lib().vrt_image_write_pfm(p, a.ctypes.data_as(C.c_void_p), W, H, a.shape[2]))
 
 
 def vox_flatten_host(buf: bytes):

@@ -45,7 +45,7 @@ std::shared_ptr<VoxelScene> loadDense(const std::shared_ptr<Engine>& engine, con
 int run(int argc, char** argv)
 {
     try {
-        std::string vox, dense, out, raw, dumpPush;
+        std::string vox, dense, out, raw, dumpPush, sky, noise, png;
         auto settings = std::make_shared<VoxelRenderSettings>();
         vec3 pos{8, 8, -50}; float yaw = 90, pitch = 0; bool havePos = false; int device = 0;
         for (int i = 1; i < argc; i++) {
@@ -53,6 +53,7 @@ int run(int argc, char** argv)
             auto next = [&]() { if (i + 1 >= argc) throw std::runtime_error("missing value for " + a); return std::string(argv[++i]); };
             if (a == "--vox") vox = next(); else if (a == "--dense") dense = next(); else if (a == "--out") out = next();
             else if (a == "--raw") raw = next(); else if (a == "--dump-push") dumpPush = next();
+            else if (a == "--sky") sky = next(); else if (a == "--noise") noise = next(); else if (a == "--png") png = next();
             else if (a == "--width") settings->targetResolution[0] = (uint32_t)std::stoul(next());
             else if (a == "--height") settings->targetResolution[1] = (uint32_t)std::stoul(next());
             else if (a == "--pos") { pos.x = std::stof(next()); pos.y = std::stof(next()); pos.z = std::stof(next()); havePos = true; }
@@ -71,6 +72,8 @@ int run(int argc, char** argv)
         std::shared_ptr<VoxelScene> scene;
         if (!dense.empty()) scene = loadDense(engine, dense);
         else scene = std::make_shared<VoxelScene>(engine, vox.empty() ? settings->voxPath : vox);
+        if (!sky.empty()) scene->setSkybox(sky);
+        if (!noise.empty()) scene->setBlueNoise(noise);
         VoxelRenderer renderer(engine, settings, scene);
         if (!havePos) pos = {scene->width / 2.0f, scene->height / 2.0f, -0.8f * scene->depth};
         renderer.camera().position = pos; renderer.camera().yaw = yaw; renderer.camera().pitch = pitch;
@@ -79,6 +82,7 @@ int run(int argc, char** argv)
         auto res = settings->renderResolution();
         if (!dumpPush.empty()) { vrt_push p = renderer.pushConstants(); std::ofstream(dumpPush, std::ios::binary).write((const char*)&p, sizeof p); }
         if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)img.data(), (std::streamsize)img.size());
+        if (!png.empty()) check(vrt_image_write_png(png.c_str(), img.data(), res[0], res[1]));
         if (!out.empty()) {
             std::ofstream f(out, std::ios::binary);
             f << "P6\n" << res[0] << " " << res[1] << "\n255\n";

@@ -138,15 +138,19 @@ public:
 class VoxelScene {
 public:
     uint32_t width = 0, height = 0, depth = 0;
-    VoxelScene(const std::shared_ptr<Engine>& engine, const std::string& filename) : engine(engine)   // voxel_scene.cpp:33
+    VoxelScene(const std::shared_ptr<Engine>& engine, const std::string& filename, const std::string& skyboxFilename = "")
+        : engine(engine)                                                                              // voxel_scene.cpp:33
     {
         check(vrt_scene_load_vox_file(engine->ctx, filename.c_str(), &handle)); dims();
+        if (!skyboxFilename.empty()) setSkybox(skyboxFilename);                                       // :132
     }
     VoxelScene(const std::shared_ptr<Engine>& engine, const uint8_t* voxels, uint32_t W, uint32_t H, uint32_t D, const vrt_material* palette)
         : engine(engine) { check(vrt_scene_from_dense(engine->ctx, voxels, W, H, D, palette, &handle)); dims(); }
     ~VoxelScene() { vrt_scene_free(engine->ctx, handle); }
     VoxelScene(const VoxelScene&) = delete; VoxelScene& operator=(const VoxelScene&) = delete;
     void setSkybox(const float* rgba, uint32_t w, uint32_t h) { check(vrt_scene_set_sky(engine->ctx, handle, rgba, w, h)); }
+    void setSkybox(const std::string& path) { check(vrt_scene_set_sky_file(engine->ctx, handle, path.c_str())); }          // Texture2D(.hdr)
+    void setBlueNoise(const std::string& path) { check(vrt_scene_set_blue_noise_file(engine->ctx, handle, path.c_str())); }   // Texture2D(.png)
     void setBlueNoise(const uint8_t* rgba8, uint32_t w, uint32_t h) { check(vrt_scene_set_blue_noise(engine->ctx, handle, rgba8, w, h)); }
     vrt_scene* handle = nullptr;
 private:
