@@ -235,6 +235,27 @@ int  vrt_unpack_halo(vrt_ctx* ctx, const void* packed, void* full, int32_t W, in
                      int32_t bytes_per_px, const vrt_shard* shard, int32_t halo, int32_t dir);
 size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bytes_per_px, const vrt_shard* shard, int32_t halo);
 
+/* ---- presentation / temporal helpers ----------------------------------- */
+/* Replaces BlitStage::record + shader/blit.frag:14-22 (source/voxels/stages/blit_stage.cpp:41-75): the RGBA8 source
+ * is centre-cropped to the target's aspect ratio and resampled with a linear, clamp-to-edge sampler
+ * (render_image.cpp:61-66).  Also the plain upscale of a reduced-resolution render
+ * (voxel_render_settings.cpp:3-13) that stands in for the FSR2 dispatch (upscaler_stage.cpp:72-161, out of scope).
+ * Device pointers; runs on the context's stream. */
+int  vrt_blit(vrt_ctx* ctx, const void* src_rgba8, int32_t src_w, int32_t src_h,
+              void* dst_rgba8, int32_t dst_w, int32_t dst_h);
+
+/* N-frame accumulation of jittered frames, the offline stand-in for FSR2's temporal pass: accum is W*H*4 uint32
+ * (device), holding exact sums of the UNORM8 codes; reset != 0 starts a new sequence with this frame.
+ * vrt_resolve writes the mean of `frames` accumulated frames, rounded half up: (2*sum + frames) / (2*frames). */
+int  vrt_accumulate(vrt_ctx* ctx, const void* color_rgba8, void* accum_u32, int32_t W, int32_t H, int32_t reset);
+int  vrt_resolve(vrt_ctx* ctx, const void* accum_u32, void* out_rgba8, int32_t W, int32_t H, uint32_t frames);
+
+/* Replace ffxFsr2GetJitterPhaseCount / ffxFsr2GetJitterOffset as called by UpscalerStage::update
+ * (source/voxels/stages/upscaler_stage.cpp:59-70): phase count int(8 * (display_width / render_width)^2);
+ * offset = Halton(2,3)(index % phase_count + 1) - 0.5, in pixels; feeds vrt_push.camera_jitter. */
+int32_t vrt_jitter_phase_count(int32_t render_width, int32_t display_width);
+int  vrt_jitter_offset(int32_t index, int32_t phase_count, float* jitter_x, float* jitter_y);
+
 /* ---- instrumentation ------------------------------------------------------------------------- */
 /* Time of the most recent vrt_render_geometry primary-ray kernel / all its kernels, and of the most
  * recent vrt_denoise, in milliseconds (HIP events on the context stream; blocks until they complete). */

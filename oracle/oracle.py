@@ -87,8 +87,27 @@ def lib():
         l.vo_denoise.restype = C.c_int
         l.vo_denoise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+        l.vo_blit.restype = None
+        l.vo_blit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        l.vo_jitter_phase_count.restype = C.c_int; l.vo_jitter_phase_count.argtypes = [C.c_int, C.c_int]
+        l.vo_jitter_offset.restype = None
+        l.vo_jitter_offset.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib = l
     return _lib
+
+
+def blit(src, tw, th):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((th, tw, 4), np.uint8)
+    lib().vo_blit(src.ctypes.data, src.shape[1], src.shape[0], dst.ctypes.data, tw, th)
+    return dst
+
+
+def jitter(index, render_width, display_width):
+    n = lib().vo_jitter_phase_count(render_width, display_width)
+    x, y = C.c_float(), C.c_float()
+    lib().vo_jitter_offset(index, n, C.byref(x), C.byref(y))
+    return n, x.value, y.value
 
 
 class OracleScene:

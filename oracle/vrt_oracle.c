@@ -641,3 +641,63 @@ int vo_denoise(const uint8_t* color_in, const int8_t* normal, const float* posit
     }
     return last;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* blit + jitter (rows "next" of SURVEY 8(f))                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* texture(inputImage, uv) with a linear / clamp-to-edge sampler on an RGBA8_UNORM image */
+static void sample_rgba8_linear(const uint8_t* img, int w, int h, float u, float v, float out[4])
+{
+    float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float tx = fx - x0f, ty = fy - y0f;
+    int x0 = clampi((int)x0f, 0, w - 1), x1 = clampi((int)x0f + 1, 0, w - 1);
+    int y0 = clampi((int)y0f, 0, h - 1), y1 = clampi((int)y0f + 1, 0, h - 1);
+    for (int k = 0; k < 4; k++) {
+        float c00 = (float)img[((size_t)y0 * w + x0) * 4 + k] / 255.0f, c10 = (float)img[((size_t)y0 * w + x1) * 4 + k] / 255.0f;
+        float c01 = (float)img[((size_t)y1 * w + x0) * 4 + k] / 255.0f, c11 = (float)img[((size_t)y1 * w + x1) * 4 + k] / 255.0f;
+        float a = c00 + tx * (c10 - c00), b = c01 + tx * (c11 - c01);
+        out[k] = a + ty * (b - a);
+    }
+}
+
+/* blit.frag:14-22 */
+void vo_blit(const uint8_t* src, int sw, int sh, uint8_t* dst, int tw, int th)
+{
+    float sx = (float)sw, sy = (float)sh, txs = (float)tw, tys = (float)th;
+    float scale = fminf(sx / txs, sy / tys);
+    float stx = txs * scale, sty = tys * scale;                    /* scaledTarget */
+    for (int py = 0; py < th; py++)
+        for (int px = 0; px < tw; px++) {
+            float vx = ((float)px + 0.5f) / txs, vy = ((float)py + 0.5f) / tys;   /* vScreenPos */
+            float tpx = vx * txs, tpy = vy * tys;                                   /* targetPos  */
+            float spx = tpx * scale + (sx - stx) / 2.0f, spy = tpy * scale + (sy - sty) / 2.0f;
+            float c[4];
+            sample_rgba8_linear(src, sw, sh, spx / sx, spy / sy, c);
+            for (int k = 0; k < 4; k++) dst[((size_t)py * tw + px) * 4 + k] = vo_unorm8(c[k]);
+        }
+}
+
+int vo_jitter_phase_count(int render_width, int display_width)
+{
+    float r = (float)display_width / (float)render_width;
+    return (int)(8.0f * (r * r));                                 /* powf(r, 2.0f) == r*r exactly */
+}
+
+static float halton(int index, int base)
+{
+    float f = 1.0f, result = 0.0f;
+    for (int i = index; i > 0; i = i / base) {
+        f /= (float)base;
+        result += f * (float)(i % base);
+    }
+    return result;
+}
+
+void vo_jitter_offset(int index, int phase_count, float* jx, float* jy)
+{
+    int i = (index % phase_count) + 1;
+    *jx = halton(i, 2) - 0.5f;
+    *jy = halton(i, 3) - 0.5f;
+}

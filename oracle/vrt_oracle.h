@@ -143,6 +143,15 @@ int vo_denoise(const uint8_t* color_in, const int8_t* normal, const float* posit
                uint8_t* target0, uint8_t* target1, int W, int H, int iterations,
                float phi_color0, float phi_normal0, float phi_pos0, float step_width0, int mode);
 
+/* blit.frag:14-22 (BlitStage, source/voxels/stages/blit_stage.cpp:41-43): centre-crop / scale the source image into
+ * the target with a linear, clamp-to-edge sampler (render_image.cpp:61-66).  RGBA8 in, RGBA8 out. */
+void vo_blit(const uint8_t* src, int sw, int sh, uint8_t* dst, int tw, int th);
+
+/* Jitter sequence of UpscalerStage::update (upscaler_stage.cpp:59-70) with FidelityFX-FSR2's published helpers
+ * (ffxFsr2GetJitterPhaseCount = int(8 * (display/render)^2), ffxFsr2GetJitterOffset = Halton(2,3) - 0.5 in pixels). */
+int  vo_jitter_phase_count(int render_width, int display_width);
+void vo_jitter_offset(int index, int phase_count, float* jx, float* jy);
+
 /* Math primitives exported for the accuracy tests. */
 float vo_atan2f(float y, float x);
 float vo_asinf(float x);

@@ -58,3 +58,39 @@ def test_cpp_app_error_behaviour(tmp_path):
     r = subprocess.run([APP, "--vox", os.path.join(ROOT, "tests", "golden", "vox_multi.vox"), "--width", "64", "--height", "48",
                         "--primary-only", "--no-denoise", "--no-fsr", "--raw", str(tmp_path / "o.rgba")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and os.path.getsize(tmp_path / "o.rgba") == 64 * 48 * 4
+
+
+def test_cpp_app_temporal_window(vrt, oracle, tmp_path):
+    """--frames 3 --temporal --window: UpscalerStage::update jitter sequence + accumulation stand-in + BlitStage in the
+    C++ mirror, against the oracle replaying the same three push-constant blocks."""
+    vol = vrt.synthetic.floating_cubes(40, seed=11, count=50)
+    pal = metallic_palette(vrt)
+    sky, noise = vrt.synthetic.sky_gradient(64, 32), vrt.synthetic.blue_noise_standin(64)
+    dense = tmp_path / "scene.vrtd"
+    _write_dense(dense, vol, pal, sky, noise)
+    raw, pushf = tmp_path / "out.rgba", tmp_path / "push.bin"
+    r = subprocess.run([APP, "--dense", str(dense), "--width", "160", "--height", "96", "--pos", "20.3", "20.2", "-30", "--ao", "1",
+                        "--frames", "3", "--temporal", "--window", "100", "100", "--raw", str(raw), "--dump-push", str(pushf),
+                        "--png", str(tmp_path / "o.png")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    last = oracle.Push.from_buffer_copy(pushf.read_bytes())
+    RW, RH = last.screen_size[0], last.screen_size[1]
+    assert (RW, RH) == (94, 56) and last.frame == 3                       # BALANCED scale of 160x96
+    st = vrt.VoxelRenderSettings(targetResolution=(160, 96))
+    st.occlusionSettings.numSamples = 1
+    osn, pr = oracle.OracleScene(vol, pal, sky=sky, noise=noise), oracle.params_from(st.to_c())
+    acc = np.zeros((RH, RW, 4), np.int64)
+    for f in range(3):
+        push = oracle.Push.from_buffer_copy(pushf.read_bytes())
+        _, jx, jy = oracle.jitter(f, RW, 160)
+        push.frame = f + 1
+        push.camera_jitter[0], push.camera_jitter[1] = jx, jy
+        fr = oracle.render(osn, push, pr, planes=["color8", "normal8", "position"])
+        acc += oracle.denoise(fr["color8"], fr["normal8"], fr["position"])
+    assert (last.camera_jitter[0], last.camera_jitter[1]) == (np.float32(jx), np.float32(jy))
+    mean = ((2 * acc + 3) // 6).astype(np.uint8)
+    exp = oracle.blit(oracle.blit(mean, 160, 96), 100, 100)
+    got = np.frombuffer(raw.read_bytes(), np.uint8).reshape(100, 100, 4)
+    assert (got == exp).all(), int((got != exp).sum())
+    img = vrt.load_image(str(tmp_path / "o.png"))
+    assert img.shape[:2] == (100, 100)

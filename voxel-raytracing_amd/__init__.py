@@ -5,9 +5,9 @@ this package is the Python host side (ctypes) mirroring the reference's objects.
 from . import _capi
 from ._capi import (TRAVERSAL_AUTO, TRAVERSAL_DENSE, TRAVERSAL_BITMASK, TRAVERSAL_JUMP, TRAVERSAL_DF, TRAVERSAL_DFJ,
                     DENOISE_CANONICAL, DENOISE_AS_SHIPPED, VrtError, lib)
-from .host import (AmbientOcclusionSettings, CameraController, DenoiserSettings, DenoiserStage, Engine,
+from .host import (AmbientOcclusionSettings, BlitStage, CameraController, CameraKey, DenoiserSettings, DenoiserStage, Engine,
                    FsrScaling, FsrSettings, GeometryBuffer, GeometryStage, LightSettings, TraceSettings,
-                   VoxelRenderSettings, VoxelRenderer, VoxelScene, load_image, make_push, make_shard, vox_flatten_host,
+                   UpscalerStage, camera_path,                   VoxelRenderSettings, VoxelRenderer, VoxelScene, load_image, make_push, make_shard, vox_flatten_host,
                    write_image)
 from . import synthetic
 from . import distributed

@@ -100,6 +100,11 @@ SYMBOLS = {
     "vrt_pack_halo": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
     "vrt_unpack_halo": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
     "vrt_halo_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32]),
+    "vrt_blit": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32]),
+    "vrt_accumulate": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32]),
+    "vrt_resolve": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_uint32]),
+    "vrt_jitter_phase_count": (C.c_int32, [C.c_int32, C.c_int32]),
+    "vrt_jitter_offset": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vrt_last_timings": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vrt_ctx_set_timing": (C.c_int, [_P, C.c_int]),
 }

@@ -627,6 +627,70 @@ size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bpp, const vrt_shard* sh, in
     return (size_t)mx * (size_t)halo * (size_t)W * (size_t)bpp;
 }
 
+// ---- presentation / temporal helpers ---------------------------------------------------------------
+
+int vrt_blit(vrt_ctx* c, const void* src_rgba8, int32_t sw, int32_t sh, void* dst_rgba8, int32_t tw, int32_t th)
+{
+    if (!c || !src_rgba8 || !dst_rgba8) return fail(VRT_ERR_INVALID, "vrt_blit: NULL argument");
+    if (sw <= 0 || sh <= 0 || tw <= 0 || th <= 0) return fail(VRT_ERR_INVALID, "vrt_blit: bad size");
+    if (src_rgba8 == dst_rgba8) return fail(VRT_ERR_INVALID, "vrt_blit: source and target must differ");
+    HIPCHK(hipSetDevice(c->device));
+    BlitParams p;
+    p.src = (const uint8_t*)src_rgba8; p.dst = (uint8_t*)dst_rgba8; p.sw = sw; p.sh = sh; p.tw = tw; p.th = th;
+    HIPCHK(launch_blit(p, c->stream));
+    return VRT_OK;
+}
+
+int vrt_accumulate(vrt_ctx* c, const void* color_rgba8, void* accum_u32, int32_t W, int32_t H, int32_t reset)
+{
+    if (!c || !color_rgba8 || !accum_u32) return fail(VRT_ERR_INVALID, "vrt_accumulate: NULL argument");
+    if (W <= 0 || H <= 0) return fail(VRT_ERR_INVALID, "vrt_accumulate: bad size");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_accumulate(color_rgba8, accum_u32, (size_t)W * (size_t)H, reset != 0, c->stream));
+    return VRT_OK;
+}
+
+int vrt_resolve(vrt_ctx* c, const void* accum_u32, void* out_rgba8, int32_t W, int32_t H, uint32_t frames)
+{
+    if (!c || !accum_u32 || !out_rgba8) return fail(VRT_ERR_INVALID, "vrt_resolve: NULL argument");
+    if (W <= 0 || H <= 0) return fail(VRT_ERR_INVALID, "vrt_resolve: bad size");
+    if (frames == 0 || frames > (1u << 22)) return fail(VRT_ERR_INVALID, "vrt_resolve: frames must be in 1..2^22");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_resolve(accum_u32, out_rgba8, (size_t)W * (size_t)H, frames, c->stream));
+    return VRT_OK;
+}
+
+// ffxFsr2GetJitterPhaseCount / ffxFsr2GetJitterOffset as documented in FidelityFX-FSR2's ffx_fsr2.h (the prebuilt
+// library the reference links is absent from its tree): phase count int(8 * (display/render)^2), offset
+// Halton(2,3)(index % phases + 1) - 0.5 in pixel units.  Host-only arithmetic (two floats per frame).
+int32_t vrt_jitter_phase_count(int32_t render_width, int32_t display_width)
+{
+    if (render_width <= 0 || display_width <= 0) return 0;
+    const float ratio = (float)display_width / (float)render_width;
+    return (int32_t)(8.0f * (ratio * ratio));
+}
+
+static float radical_inverse(int32_t index, int32_t base)
+{
+    float digit = 1.0f, acc = 0.0f;
+    while (index > 0) {
+        digit /= (float)base;
+        acc += digit * (float)(index % base);
+        index /= base;
+    }
+    return acc;
+}
+
+int vrt_jitter_offset(int32_t index, int32_t phase_count, float* jitter_x, float* jitter_y)
+{
+    if (!jitter_x || !jitter_y) return fail(VRT_ERR_INVALID, "vrt_jitter_offset: NULL argument");
+    if (phase_count <= 0 || index < 0) return fail(VRT_ERR_INVALID, "vrt_jitter_offset: index >= 0 and phase_count > 0 required");
+    const int32_t k = index % phase_count + 1;
+    *jitter_x = radical_inverse(k, 2) - 0.5f;
+    *jitter_y = radical_inverse(k, 3) - 0.5f;
+    return VRT_OK;
+}
+
 // ---- instrumentation -------------------------------------------------------------------------------
 
 int vrt_last_timings(vrt_ctx* c, float* primary_ms, float* geometry_ms, float* denoise_ms)

@@ -828,4 +828,89 @@ hipError_t launch_rows(const RowsParams& p, int rows_total, hipStream_t s)
     return hipGetLastError();
 }
 
+// ======================================================================================================
+// Presentation / temporal helpers: all three are pure streaming kernels, one
+// thread per pixel, one wave = 64 consecutive pixels of a row (256 B coalesced RGBA8 accesses).
+// ======================================================================================================
+
+// blit.frag:14-22 with the BlitStage sampler (linear filter, clamp-to-edge; render_image.cpp:61-66): the source
+// is centre-cropped to the target's aspect ratio and scaled.  Serves as the plain upscale of a reduced-resolution
+// render (voxel_render_settings.cpp:3-13) and as the letterbox copy to a window-sized target.
+__global__ __launch_bounds__(256) void k_blit(BlitParams p)
+{
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= p.tw || py >= p.th) return;
+    const float sx = (float)p.sw, sy = (float)p.sh, tx = (float)p.tw, ty = (float)p.th;
+    const float scale = fminf(sx / tx, sy / ty);
+    const float stx = tx * scale, sty = ty * scale;
+    const float vx = ((float)px + 0.5f) / tx, vy = ((float)py + 0.5f) / ty;
+    const float spx = (vx * tx) * scale + (sx - stx) / 2.0f, spy = (vy * ty) * scale + (sy - sty) / 2.0f;
+    const float u = spx / sx, v = spy / sy;
+    const float fx = u * sx - 0.5f, fy = v * sy - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int x0 = min(max((int)x0f, 0), p.sw - 1), x1 = min(max((int)x0f + 1, 0), p.sw - 1);
+    const int y0 = min(max((int)y0f, 0), p.sh - 1), y1 = min(max((int)y0f + 1, 0), p.sh - 1);
+    const uchar4* src = reinterpret_cast<const uchar4*>(p.src);
+    const uchar4 t00 = src[(size_t)y0 * p.sw + x0], t10 = src[(size_t)y0 * p.sw + x1];
+    const uchar4 t01 = src[(size_t)y1 * p.sw + x0], t11 = src[(size_t)y1 * p.sw + x1];
+    auto mix = [&](uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) -> uint8_t {
+        const float f00 = decode_unorm8(c00), f10 = decode_unorm8(c10), f01 = decode_unorm8(c01), f11 = decode_unorm8(c11);
+        const float a = f00 + wx * (f10 - f00), b = f01 + wx * (f11 - f01);
+        return unorm8(a + wy * (b - a));
+    };
+    uchar4 o;
+    o.x = mix(t00.x, t10.x, t01.x, t11.x); o.y = mix(t00.y, t10.y, t01.y, t11.y);
+    o.z = mix(t00.z, t10.z, t01.z, t11.z); o.w = mix(t00.w, t10.w, t01.w, t11.w);
+    reinterpret_cast<uchar4*>(p.dst)[(size_t)py * p.tw + px] = o;
+}
+
+hipError_t launch_blit(const BlitParams& p, hipStream_t s)
+{
+    if (p.tw <= 0 || p.th <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_blit, dim3((unsigned)((p.tw + 63) / 64), (unsigned)((p.th + 3) / 4)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// N-frame accumulation of jittered frames (the offline stand-in for the FSR2 temporal pass): exact integer sums of the
+// UNORM8 codes, so the result does not depend on the order the frames arrive in.
+__global__ __launch_bounds__(256) void k_accumulate(const uchar4* __restrict__ color, uint4* __restrict__ accum, size_t n, int reset)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uchar4 c = color[i];
+    uint4 a = reset ? make_uint4(0, 0, 0, 0) : accum[i];
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+    accum[i] = a;
+}
+
+// mean of `frames` codes, rounded half up: (2*sum + frames) / (2*frames) in integers.
+__global__ __launch_bounds__(256) void k_resolve(const uint4* __restrict__ accum, uchar4* __restrict__ out, size_t n, uint32_t frames)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 a = accum[i];
+    const uint32_t d = 2u * frames;
+    uchar4 o;
+    o.x = (uint8_t)min((2u * a.x + frames) / d, 255u); o.y = (uint8_t)min((2u * a.y + frames) / d, 255u);
+    o.z = (uint8_t)min((2u * a.z + frames) / d, 255u); o.w = (uint8_t)min((2u * a.w + frames) / d, 255u);
+    out[i] = o;
+}
+
+hipError_t launch_accumulate(const void* color, void* accum, size_t n, int reset, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       (const uchar4*)color, (uint4*)accum, n, reset);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const void* accum, void* out, size_t n, uint32_t frames, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       (const uint4*)accum, (uchar4*)out, n, frames);
+    return hipGetLastError();
+}
+
 } // namespace vrt

@@ -86,6 +86,11 @@ struct RowsParams {
     int32_t halo, dir, unpack;
 };
 
+struct BlitParams {
+    const uint8_t* src; uint8_t* dst;
+    int32_t sw, sh, tw, th;
+};
+
 // launchers (vrt_device.hip)
 hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_t* occ1, uint64_t* occ2,
                                 uint64_t* occ3, hipStream_t s);
@@ -94,6 +99,9 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s);
 hipError_t launch_shade(const GeomParams& p, hipStream_t s);
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s);
 hipError_t launch_rows(const RowsParams& p, int rows_total, hipStream_t s);
+hipError_t launch_blit(const BlitParams& p, hipStream_t s);
+hipError_t launch_accumulate(const void* color_rgba8, void* accum_u32x4, size_t n, int reset, hipStream_t s);
+hipError_t launch_resolve(const void* accum_u32x4, void* out_rgba8, size_t n, uint32_t frames, hipStream_t s);
 const char* primary_kernel_name(int traversal, int fused, int occ2_lds);
 
 } // namespace vrt

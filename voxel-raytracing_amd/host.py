@@ -175,6 +175,33 @@ class CameraController:
                          + self.right * cameraSpeed * _f32(delta) * _f32(strafe)).astype(np.float32)
         self.updateDirectionVectors()
 
+    def mouse(self, offsetX: float, offsetY: float):                        # :46-68 (right button held)
+        self.yaw -= float(_f32(offsetX))
+        self.pitch = float(min(max(_f32(self.pitch) - _f32(offsetY), _f32(-90.0)), _f32(90.0)))
+        self.updateDirectionVectors()
+
+
+@dataclass
+class CameraKey:
+    """One scripted input sample: what the keyboard / mouse callbacks of camera_controller.cpp:30-68 would have seen
+    during `frames` consecutive frames (W/S -> forward +-1, D/A -> strafe +-1, cursor motion in pixels per frame)."""
+    frames: int = 1
+    forward: float = 0.0
+    strafe: float = 0.0
+    mouseX: float = 0.0
+    mouseY: float = 0.0
+
+
+def camera_path(camera: CameraController, keys, delta: float = 1.0 / 60.0):
+    """Scripted fly-through: replays `keys` through CameraController.update / mouse and yields the controller after every
+    frame (the same object, mutated), so a benchmark can render an animated sequence without a window."""
+    for k in keys:
+        for _ in range(int(k.frames)):
+            if k.mouseX or k.mouseY:
+                camera.mouse(k.mouseX, k.mouseY)
+            camera.update(delta, k.forward, k.strafe)
+            yield camera
+
 
 # --------------------------------------------------------------------------------------------------
 # engine / scene
@@ -538,21 +565,95 @@ class DenoiserStage:
         return colorInput
 
 
+class UpscalerStage:
+    """UpscalerStage (upscaler_stage.cpp).  update() reproduces the jitter / frame sequence of :59-70 bit for bit
+    (including the `frameCount > phaseCount` wrap, which lets frameCount reach phaseCount once per cycle).  The FSR2
+    dispatch of record() (:72-161, a prebuilt third-party library) is out of scope; its stand-in is an exact N-frame
+    accumulation of the jittered frames followed by the bilinear upscale to targetResolution (vrt_accumulate /
+    vrt_resolve / vrt_blit)."""
+
+    def __init__(self, engine: Engine, settings: VoxelRenderSettings):
+        self.engine, self._settings = engine, settings
+        self.jitterX = 0.0
+        self.jitterY = 0.0
+        self.frameCount = 0
+        self._deltaMsec = 0.0
+        self._accum = self._resolved = self._target = None
+        self.accumulated = 0
+
+    def phaseCount(self) -> int:
+        return int(lib().vrt_jitter_phase_count(self._settings.renderResolution()[0], self._settings.targetResolution[0]))
+
+    def update(self, delta: float):                                         # :59-70
+        self._deltaMsec = delta * 1000
+        phases = self.phaseCount()
+        jx, jy = C.c_float(), C.c_float()
+        check(lib().vrt_jitter_offset(self.frameCount % phases, phases, C.byref(jx), C.byref(jy)))
+        self.jitterX, self.jitterY = jx.value, jy.value
+        self.frameCount += 1
+        if self.frameCount > phases:
+            self.frameCount = 0
+
+    def reset(self):
+        """Drop the accumulated history (camera or scene changed)."""
+        self.accumulated = 0
+
+    def record(self, color):
+        torch = _torch()
+        H, W = color.shape[0], color.shape[1]
+        TW, TH = self._settings.targetResolution
+        if self._accum is None or self._accum.shape[:2] != (H, W):
+            self._accum = torch.zeros((H, W, 4), dtype=torch.int32, device=color.device)
+            self._resolved = torch.zeros((H, W, 4), dtype=torch.uint8, device=color.device)
+            self.accumulated = 0
+        if self._target is None or self._target.shape[:2] != (TH, TW):
+            self._target = torch.zeros((TH, TW, 4), dtype=torch.uint8, device=color.device)
+        check(lib().vrt_accumulate(self.engine.ctx, color.data_ptr(), self._accum.data_ptr(), W, H, 1 if self.accumulated == 0 else 0))
+        self.accumulated += 1
+        check(lib().vrt_resolve(self.engine.ctx, self._accum.data_ptr(), self._resolved.data_ptr(), W, H, self.accumulated))
+        check(lib().vrt_blit(self.engine.ctx, self._resolved.data_ptr(), W, H, self._target.data_ptr(), TW, TH))
+        return self._target
+
+
+class BlitStage:
+    """BlitStage::record + shader/blit.frag (blit_stage.cpp:41-75): centre-cropped bilinear copy into a window-sized
+    RGBA8 target (the swapchain image of the reference; here a device tensor)."""
+
+    def __init__(self, engine: Engine, settings: VoxelRenderSettings):
+        self.engine, self._settings = engine, settings
+        self._target = None
+
+    def record(self, source, windowSize):
+        torch = _torch()
+        TW, TH = int(windowSize[0]), int(windowSize[1])
+        if self._target is None or self._target.shape[:2] != (TH, TW):
+            self._target = torch.zeros((TH, TW, 4), dtype=torch.uint8, device=source.device)
+        check(lib().vrt_blit(self.engine.ctx, source.data_ptr(), source.shape[1], source.shape[0],
+                             self._target.data_ptr(), TW, TH))
+        return self._target
+
+
 class VoxelRenderer:
-    """VoxelRenderer (voxel_renderer.cpp:16-94) reduced to the hot path: scene + camera + settings ->
-    GeometryStage -> DenoiserStage -> RGBA8 image.  FSR2 / blit / GUI are out of scope; cameraJitter and
-    frame are plain inputs (default 0)."""
+    """VoxelRenderer (voxel_renderer.cpp:16-94): scene + camera + settings -> GeometryStage -> DenoiserStage ->
+    UpscalerStage stand-in -> BlitStage -> RGBA8 image.  update() advances the camera and the jitter sequence as
+    :33-39 does; until update() is called frame = 0 and cameraJitter = (0, 0).  GUI / swapchain are out of scope.
+
+    temporal=False (default) keeps the frame graph at the hot path: the FSR branch of :86-87 is skipped and the
+    image stays at renderResolution(); temporal=True takes that branch through the accumulation stand-in.
+    windowSize=(w, h) appends the blit of :89."""
 
     def __init__(self, engine: Engine, settings: Optional[VoxelRenderSettings] = None, scene: Optional[VoxelScene] = None,
-                 noise=None, debug_planes: bool = False):
+                 noise=None, debug_planes: bool = False, temporal: bool = False, windowSize=None):
         self.engine = engine
         self._settings = settings or VoxelRenderSettings()
         self._camera = CameraController()
         self._scene = scene if scene is not None else VoxelScene(engine, self._settings.voxPath)
         self._geometryStage = GeometryStage(engine, self._settings, self._scene, noise, debug_planes)
         self._denoiserStage = DenoiserStage(engine, self._settings)
-        self.frameCount = 0
-        self.jitter = (0.0, 0.0)
+        self._upscalerStage = UpscalerStage(engine, self._settings)
+        self._blitStage = BlitStage(engine, self._settings)
+        self.temporal = bool(temporal)
+        self.windowSize = windowSize
         self._time = 0.0
 
     @property
@@ -567,9 +668,31 @@ class VoxelRenderer:
     def scene(self):
         return self._scene
 
-    def update(self, delta: float, forward=0.0, strafe=0.0):          # :33-53
+    @property
+    def upscaler(self):
+        return self._upscalerStage
+
+    # frame / jitter live in the upscaler stage as in the reference (voxel_renderer.cpp:80-82)
+    @property
+    def frameCount(self):
+        return self._upscalerStage.frameCount
+
+    @frameCount.setter
+    def frameCount(self, v):
+        self._upscalerStage.frameCount = int(v)
+
+    @property
+    def jitter(self):
+        return (self._upscalerStage.jitterX, self._upscalerStage.jitterY)
+
+    @jitter.setter
+    def jitter(self, v):
+        self._upscalerStage.jitterX, self._upscalerStage.jitterY = float(v[0]), float(v[1])
+
+    def update(self, delta: float, forward=0.0, strafe=0.0):          # :33-39
         self._time += delta
         self._camera.update(delta, forward, strafe)
+        self._upscalerStage.update(delta)
 
     def push_constants(self) -> _capi.Push:                           # :72-83
         return make_push(self._camera, (self._scene.width, self._scene.height, self._scene.depth),
@@ -583,6 +706,10 @@ class VoxelRenderer:
         else:
             color = gBuffer.color
         self.gBuffer = gBuffer
+        if self.temporal and self._settings.fsrSetttings.enable:      # :86-87
+            color = self._upscalerStage.record(color)
+        if self.windowSize is not None:                               # :89
+            color = self._blitStage.record(color, self.windowSize)
         return color
 
     render = recordCommands

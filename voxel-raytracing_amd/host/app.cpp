@@ -48,6 +48,7 @@ int run(int argc, char** argv)
         std::string vox, dense, out, raw, dumpPush, sky, noise, png;
         auto settings = std::make_shared<VoxelRenderSettings>();
         vec3 pos{8, 8, -50}; float yaw = 90, pitch = 0; bool havePos = false; int device = 0;
+        int frames = 1; uint32_t windowW = 0, windowH = 0; float flyForward = 0, flyStrafe = 0, flyMouseX = 0; bool temporal = false;
         for (int i = 1; i < argc; i++) {
             std::string a = argv[i];
             auto next = [&]() { if (i + 1 >= argc) throw std::runtime_error("missing value for " + a); return std::string(argv[++i]); };
@@ -66,6 +67,10 @@ int run(int argc, char** argv)
             else if (a == "--no-shadows") settings->traceSettings.shadows = false;
             else if (a == "--primary-only") { settings->occlusionSettings.numSamples = 0; settings->traceSettings.shadows = false; settings->traceSettings.maxReflections = 0; }
             else if (a == "--device") device = std::stoi(next());
+            else if (a == "--frames") frames = std::max(1, std::stoi(next()));                 // frames to run (update + render each)
+            else if (a == "--temporal") temporal = true;                                       // accumulate jittered frames + upscale
+            else if (a == "--window") { windowW = (uint32_t)std::stoul(next()); windowH = (uint32_t)std::stoul(next()); }
+            else if (a == "--fly") { flyForward = std::stof(next()); flyStrafe = std::stof(next()); flyMouseX = std::stof(next()); }
             else throw std::runtime_error("unknown argument " + a);
         }
         auto engine = std::make_shared<Engine>(device);
@@ -78,8 +83,17 @@ int run(int argc, char** argv)
         if (!havePos) pos = {scene->width / 2.0f, scene->height / 2.0f, -0.8f * scene->depth};
         renderer.camera().position = pos; renderer.camera().yaw = yaw; renderer.camera().pitch = pitch;
         renderer.camera().updateDirectionVectors();
-        std::vector<uint8_t> img = renderer.render();
-        auto res = settings->renderResolution();
+        renderer.temporal = temporal; renderer.windowW = windowW; renderer.windowH = windowH;
+        std::vector<uint8_t> img; uint32_t res[2] = {0, 0};
+        const bool moving = flyForward != 0 || flyStrafe != 0 || flyMouseX != 0;
+        for (int f = 0; f < frames; f++) {                                                     // App::run loop (source/app.cpp:18-27)
+            if (frames > 1 || temporal) {
+                if (flyMouseX != 0) renderer.camera().mouse(flyMouseX, 0.0f);
+                renderer.update(1.0f / 60.0f, flyForward, flyStrafe);
+                if (moving) renderer.upscaler().reset();                                       // no reprojection: history is per pose
+            }
+            img = renderer.render(&res[0], &res[1]);
+        }
         if (!dumpPush.empty()) { vrt_push p = renderer.pushConstants(); std::ofstream(dumpPush, std::ios::binary).write((const char*)&p, sizeof p); }
         if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)img.data(), (std::streamsize)img.size());
         if (!png.empty()) check(vrt_image_write_png(png.c_str(), img.data(), res[0], res[1]));

@@ -105,6 +105,12 @@ public:
         position = position + normalDir * (cameraSpeed * delta * forward) + right * (cameraSpeed * delta * strafe);
         updateDirectionVectors();
     }
+    void mouse(float offsetX, float offsetY)                              // :46-68 with the right button held
+    {
+        yaw -= offsetX;
+        pitch = std::min(std::max(pitch - offsetY, -90.0f), 90.0f);
+        updateDirectionVectors();
+    }
 };
 
 // ---- engine -------------------------------------------------------------------------------------------
@@ -206,14 +212,65 @@ private:
     std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> settings; std::shared_ptr<DeviceBuffer<uint8_t>> targets[2];
 };
 
+// UpscalerStage (upscaler_stage.cpp): update() is the reference's jitter / frame sequence (:59-70); record() replaces the
+// FSR2 dispatch (:72-161, prebuilt third party, out of scope) by exact N-frame accumulation + bilinear upscale.
+class UpscalerStage {
+public:
+    float jitterX = 0, jitterY = 0; int frameCount = 0; uint32_t accumulated = 0;
+    UpscalerStage(const std::shared_ptr<Engine>& engine, const std::shared_ptr<VoxelRenderSettings>& settings) : engine(engine), settings(settings) {}
+    int32_t phaseCount() const { return vrt_jitter_phase_count((int32_t)settings->renderResolution()[0], (int32_t)settings->targetResolution[0]); }
+    void update(float delta)                                                           // :59-70
+    {
+        _deltaMsec = delta * 1000;
+        const int32_t jitterPhaseCount = phaseCount();
+        check(vrt_jitter_offset(frameCount % jitterPhaseCount, jitterPhaseCount, &jitterX, &jitterY));
+        frameCount++;
+        if (frameCount > jitterPhaseCount) frameCount = 0;
+    }
+    void reset() { accumulated = 0; }
+    const uint8_t* record(const uint8_t* color, uint32_t w, uint32_t h)
+    {
+        size_t n = (size_t)w * h * 4;
+        if (!accum || accum->count != n) { accum = std::make_shared<DeviceBuffer<uint32_t>>(engine, n); resolved = std::make_shared<DeviceBuffer<uint8_t>>(engine, n); accumulated = 0; }
+        size_t tn = (size_t)settings->targetResolution[0] * settings->targetResolution[1] * 4;
+        if (!target || target->count != tn) target = std::make_shared<DeviceBuffer<uint8_t>>(engine, tn);
+        check(vrt_accumulate(engine->ctx, color, accum->ptr, (int32_t)w, (int32_t)h, accumulated == 0));
+        accumulated++;
+        check(vrt_resolve(engine->ctx, accum->ptr, resolved->ptr, (int32_t)w, (int32_t)h, accumulated));
+        check(vrt_blit(engine->ctx, resolved->ptr, (int32_t)w, (int32_t)h, target->ptr, (int32_t)settings->targetResolution[0], (int32_t)settings->targetResolution[1]));
+        return target->ptr;
+    }
+private:
+    std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> settings; float _deltaMsec = 0;
+    std::shared_ptr<DeviceBuffer<uint32_t>> accum; std::shared_ptr<DeviceBuffer<uint8_t>> resolved, target;
+};
+
+// BlitStage::record + shader/blit.frag (blit_stage.cpp:41-75): centre-cropped bilinear copy to a window-sized target.
+class BlitStage {
+public:
+    BlitStage(const std::shared_ptr<Engine>& engine, const std::shared_ptr<VoxelRenderSettings>& settings) : engine(engine), settings(settings) {}
+    const uint8_t* record(const uint8_t* source, uint32_t sw, uint32_t sh, uint32_t tw, uint32_t th)
+    {
+        size_t n = (size_t)tw * th * 4;
+        if (!target || target->count != n) target = std::make_shared<DeviceBuffer<uint8_t>>(engine, n);
+        check(vrt_blit(engine->ctx, source, (int32_t)sw, (int32_t)sh, target->ptr, (int32_t)tw, (int32_t)th));
+        return target->ptr;
+    }
+private:
+    std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> settings; std::shared_ptr<DeviceBuffer<uint8_t>> target;
+};
+
 // ---- renderer (voxel_renderer.cpp) ----------------------------------------------------------------------
 class VoxelRenderer {
 public:
     VoxelRenderer(const std::shared_ptr<Engine>& engine, const std::shared_ptr<VoxelRenderSettings>& settings, const std::shared_ptr<VoxelScene>& scene)
         : engine(engine), _settings(settings), _scene(scene), _camera(std::make_unique<CameraController>()),
-          _geometryStage(std::make_unique<GeometryStage>(engine, settings, scene)), _denoiserStage(std::make_unique<DenoiserStage>(engine, settings)) {}
+          _geometryStage(std::make_unique<GeometryStage>(engine, settings, scene)), _denoiserStage(std::make_unique<DenoiserStage>(engine, settings)),
+          _upscalerStage(std::make_unique<UpscalerStage>(engine, settings)), _blitStage(std::make_unique<BlitStage>(engine, settings)) {}
     CameraController& camera() { return *_camera; }
-    void update(float delta, float forward = 0.0f, float strafe = 0.0f) { _time += delta; _camera->update(delta, forward, strafe); }   // :33
+    UpscalerStage& upscaler() { return *_upscalerStage; }
+    void update(float delta, float forward = 0.0f, float strafe = 0.0f)               // :33-39
+    { _time += delta; _camera->update(delta, forward, strafe); _upscalerStage->update(delta); }
     vrt_push pushConstants() const                                                     // :72-83
     {
         vrt_push p{}; auto res = _settings->renderResolution();
@@ -224,24 +281,32 @@ public:
         p.cam_dir[0] = c.direction.x; p.cam_dir[1] = c.direction.y; p.cam_dir[2] = c.direction.z;
         p.cam_up[0] = c.up.x; p.cam_up[1] = c.up.y; p.cam_up[2] = c.up.z;
         p.cam_right[0] = c.right.x; p.cam_right[1] = c.right.y; p.cam_right[2] = c.right.z;
-        p.frame = frameCount; p.camera_jitter[0] = jitterX; p.camera_jitter[1] = jitterY;
+        p.frame = (uint32_t)_upscalerStage->frameCount;                                // :80-82
+        p.camera_jitter[0] = _upscalerStage->jitterX; p.camera_jitter[1] = _upscalerStage->jitterY;
         return p;
     }
-    // recordCommands (:55-94) reduced to the hot path; returns the RGBA8 image (host copy)
-    std::vector<uint8_t> render()
+    // recordCommands (:55-94); returns the RGBA8 image (host copy) and its size in outW / outH.
+    // temporal: take the FSR branch (:86-87) through the accumulation stand-in; windowW/H != 0: append the blit (:89).
+    std::vector<uint8_t> render(uint32_t* outW = nullptr, uint32_t* outH = nullptr)
     {
         vrt_push push = pushConstants();
         GeometryBuffer g = _geometryStage->record(push);
         const uint8_t* img = _settings->denoiserSettings.enable ? _denoiserStage->record(g) : g.color->ptr;
-        std::vector<uint8_t> host((size_t)g.width * g.height * 4);
+        uint32_t w = g.width, h = g.height;
+        if (temporal && _settings->fsrSetttings.enable) { img = _upscalerStage->record(img, w, h); w = _settings->targetResolution[0]; h = _settings->targetResolution[1]; }
+        if (windowW && windowH) { img = _blitStage->record(img, w, h, windowW, windowH); w = windowW; h = windowH; }
+        std::vector<uint8_t> host((size_t)w * h * 4);
         check(vrt_memcpy_d2h(engine->ctx, host.data(), img, host.size()));
         gBuffer = g;
+        if (outW) *outW = w;
+        if (outH) *outH = h;
         return host;
     }
-    uint32_t frameCount = 0; float jitterX = 0, jitterY = 0; GeometryBuffer gBuffer;
+    bool temporal = false; uint32_t windowW = 0, windowH = 0; GeometryBuffer gBuffer;
 private:
     std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> _settings; std::shared_ptr<VoxelScene> _scene;
     std::unique_ptr<CameraController> _camera; std::unique_ptr<GeometryStage> _geometryStage; std::unique_ptr<DenoiserStage> _denoiserStage;
+    std::unique_ptr<UpscalerStage> _upscalerStage; std::unique_ptr<BlitStage> _blitStage;
     float _time = 0;
 };
 
