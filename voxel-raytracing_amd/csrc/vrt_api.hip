@@ -493,6 +493,9 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     p.tiles_y_local = p.sh.n_local_strips * (p.sh.strip_rows / p.tile_h);
     p.total_tiles = p.tiles_x * p.tiles_y_local;
     p.chunk = p.tiles_x * ceil_div(p.tiles_y_local, 8);      // workgroups per XCD slot (tile rows are dealt round-robin)
+    p.tps = (uint32_t)(p.sh.strip_rows / p.tile_h);
+    p.tiles_x_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tiles_x);
+    p.tps_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tps);
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
     p.occ2_bytes = s->occ2_bytes; p.occ3_bytes = s->occ3_bytes;

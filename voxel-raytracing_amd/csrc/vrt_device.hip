@@ -314,22 +314,33 @@ __device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, cons
 // Workgroup -> screen tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
 // XCD and its private 4 MiB L2), so XCD slot (b % 8) gets one contiguous run of `chunk` tiles in
 // row-major tile order: neighbouring tiles traverse neighbouring volume cells and share L2 lines.
+// n / d for wave-uniform operands with rcp = floor(2^32 / d): mulhi is the quotient or one below it, one correction
+// step makes it exact for every n < 2^32.  Stays on the scalar unit (a generic 32-bit division is ~20 VALU ops).
+__device__ __forceinline__ uint32_t udiv_uniform(uint32_t n, uint32_t d, uint32_t rcp, uint32_t& rem)
+{
+    uint32_t q = (uint32_t)(((uint64_t)n * (uint64_t)rcp) >> 32);
+    uint32_t r = n - q * d;
+    if (r >= d) { q++; r -= d; }
+    rem = r;
+    return q;
+}
+
 __device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y0)
 {
-    int b = blockIdx.x;
+    uint32_t b = blockIdx.x;
     // XCD slot (b & 7) owns tile rows ty with ty % 8 == slot: every XCD gets an even sample of sky and
     // geometry (a contiguous band per XCD leaves the XCDs that drew the sky idle), while the tiles of one
     // row -- which walk neighbouring volume cells -- still share that XCD's L2.
-    int slot = b & 7, idx = b >> 3;
-    int tx = idx % P.tiles_x, ty = (idx / P.tiles_x) * 8 + slot;
+    uint32_t slot = b & 7u, idx = b >> 3, utx;
+    int ty = (int)(udiv_uniform(idx, (uint32_t)P.tiles_x, P.tiles_x_rcp, utx) * 8u + slot), tx = (int)utx;
     if (ty >= P.tiles_y_local) return false;
     // bottom rows first: the rows dispatched last only have the drain of the machine to hide in, and the top of a
     // frame is where the cheap sky-only tiles usually are
     ty = P.tiles_y_local - 1 - ty;
-    int tps = P.sh.strip_rows / P.tile_h;
-    int strip_local = ty / tps, within = ty % tps;
+    uint32_t within;
+    int strip_local = (int)udiv_uniform((uint32_t)ty, P.tps, P.tps_rcp, within);
     x0 = tx * P.tile_w;
-    y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + within * P.tile_h;
+    y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + (int)within * P.tile_h;
     return y0 < P.pc.screen_size[1];
 }
 

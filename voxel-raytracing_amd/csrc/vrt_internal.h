@@ -59,6 +59,8 @@ struct GeomParams {
     ShardMap   sh;
     int32_t    tile_w, tile_h; // workgroup tile in pixels: 16x16 (4 waves of 8x8) or 8x8 (one wave)
     int32_t    tiles_x, tiles_y_local, total_tiles, chunk;  // chunk = tiles per XCD slot
+    uint32_t   tiles_x_rcp, tps, tps_rcp;  // floor(2^32 / d) for the two wave-uniform divisions of tile_origin (scalar unit);
+                                       // tps = tiles per strip (strip_rows / tile_h)
     uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)
     uint32_t*  hit_count;      // K1 -> K2: number of hit pixels (zeroed before K1)
     uint32_t*  hit_list;       // K1 -> K2: their pixel indices, in arrival order

@@ -232,6 +232,55 @@ VRT_HD int steps_taken(float x)
 #endif
 }
 
+// Signed number of steps an axis took while its sideDist grew by dside: floor(dside * g + 1/2), g = +-1/delta (or 0 for
+// an axis that cannot step: its sideDist is +inf, inf - inf = NaN, and the DX9-rule multiply makes NaN * 0 = 0).
+// Two VALU ops: v_mul_legacy_f32 + v_cvt_rpi_i32_f32 (round to nearest by floor(x + 0.5) in one instruction).
+VRT_HD int steps_signed(float dside, float g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int n;
+    float q;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(q) : "v"(dside), "v"(g));
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(n) : "v"(q));
+    return n;
+#else
+    return g == 0.0f ? 0 : (int)floorf(dside * g + 0.5f);
+#endif
+}
+
+// One DDA iteration that only advances sideDist (frag:164-170 without the mapPos / mask bookkeeping).
+// Device: 8 VALU ops -- two integer mins, then per axis a v_cmpx that narrows EXEC to the lanes whose axis holds the
+// minimum and a v_add_f32 that runs under it (the compiler's form is compare + select + add = 10).  EXEC is put back
+// from a scalar copy after each axis; the scalar moves issue beside other waves' vector work.
+VRT_HD void dda_advance(DdaState& s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t txy, mn;
+    uint64_t saved;
+    asm volatile("v_min_u32 %[txy], %[x], %[y]\n\t"
+                 "v_min_u32 %[mn], %[txy], %[z]\n\t"
+                 "s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[x]\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[y]\n\t"
+                 "v_add_f32 %[y], %[y], %[dy]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_cmpx_le_u32 %[z], %[txy]\n\t"
+                 "v_add_f32 %[z], %[z], %[dz]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [txy] "=&v"(txy), [mn] "=&v"(mn), [sv] "=&s"(saved)
+                 : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz)
+                 : "vcc");
+#else
+    uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+    uint32_t mn = umin3(bx, by, bz);
+    s.sdx = bx == mn ? s.sdx + s.dx : s.sdx;
+    s.sdy = by == mn ? s.sdy + s.dy : s.sdy;
+    s.sdz = bz == mn ? s.sdz + s.dz : s.sdz;
+#endif
+}
+
 // ---- wavefront votes (device: the 64 lanes of a gfx950 wave; host tests: a single lane) ------------------
 
 VRT_HD bool wave_all(bool p)
@@ -257,15 +306,27 @@ VRT_HD uint32_t wave_min_u6(uint32_t k)
     if (__ballot(true) == ~0ull) {
         // all 64 lanes live (the common case): DPP min-scan, total in lane 63.  row_shr:1,2,4,8 fold each row of 16,
         // row_bcast:15 / :31 fold the rows; lanes without a source keep `old` = 63, the identity.
-        uint32_t v = k;
-        uint32_t t;
-        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x111, 0xf, 0xf, false); v = v < t ? v : t;
-        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x112, 0xf, 0xf, false); v = v < t ? v : t;
-        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x114, 0xf, 0xf, false); v = v < t ? v : t;
-        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x118, 0xf, 0xf, false); v = v < t ? v : t;
-        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x142, 0xa, 0xf, false); v = v < t ? v : t;
-        t = (uint32_t)__builtin_amdgcn_update_dpp(63, (int)v, 0x143, 0xc, 0xf, false); v = v < t ? v : t;
-        return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+        // v_min_u32 with the DPP modifier on its first source: one VALU op per stage (the builtin form costs three:
+        // mov, mov_dpp, min).  A lane whose DPP source does not exist is disabled for that op and keeps its value.
+        // s_nop 1 = the two wait states gfx9 needs between a VALU write of a VGPR and a DPP read of it.
+        uint32_t v = k, total;
+        asm volatile("s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_readlane_b32 %1, %0, 63\n\t"
+                     "s_nop 3"
+                     : "+v"(v), "=s"(total));
+        return total;
     }
     uint32_t m = 0;                                           // partial waves: binary search over ballots
 #pragma unroll
@@ -295,7 +356,15 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 {
     DdaState s;
     dda_setup(v, start, dir, s);
-    uint32_t mask = s.mask, material = 0, fetches = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // deltaDist = |1/dir|: keep the three values in registers of their own (otherwise the |.| is rematerialised as
+    // an extra VALU op in every iteration of the stepping loop, whose asm operands cannot take source modifiers)
+    asm volatile("" : "+v"(s.dx), "+v"(s.dy), "+v"(s.dz));
+#endif
+    uint32_t material = 0, fetches = 0;
+    // the mask of the latest iteration, one bool per axis: the compiler keeps each as a 64-bit lane mask in scalar
+    // registers (the compare results themselves), so recording it costs no vector instructions
+    bool k0 = (s.mask & 1u) != 0u, k1 = (s.mask & 2u) != 0u, k2 = (s.mask & 4u) != 0u;
     bool done = false;
     uint32_t clear = 63u;
     constexpr bool small = SMALL;                              // field below 4 GiB: 32-bit address arithmetic
@@ -304,7 +373,8 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     const uint32_t octant32 = oct * (uint32_t)v.df_stride;
     const size_t octant64 = (size_t)oct * (size_t)v.df_stride;
     const float kInf = u2f(0x7F800000u);
-    const float gx = s.dx < kInf ? fabsf(dir.x) : 0.0f, gy = s.dy < kInf ? fabsf(dir.y) : 0.0f, gz = s.dz < kInf ? fabsf(dir.z) : 0.0f;
+    // signed steps per unit of sideDist: dir is 1/(+-delta) to within an ulp; 0 for an axis that cannot step
+    const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
     uint32_t i = 0;                                            // wave-uniform: every live lane has done i iterations
     uint32_t n_outer = 0, n_long = 0;
     for (;;) {
@@ -331,37 +401,27 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         st_jump(stats, kw > 4u ? 2 : 1);
         if (kw >= 12u) n_long += kw;
         if (!done) {
-            // Only sideDist is advanced inside the run (10 VALU ops per iteration); mapPos is recovered afterwards:
-            // an axis that took n steps has grown by n (+) additions of delta, so n = rint((side - side_before) / delta)
-            // -- n <= 63 per run and the accumulated rounding error is orders of magnitude below 1/2.
+            // Only sideDist is advanced inside the run; mapPos is recovered afterwards: an axis that took n steps has
+            // grown by n (+) additions of delta, so n = round((side - side_before) / delta) -- n <= 63 per run and the
+            // accumulated rounding error is orders of magnitude below 1/2.
             const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
             // kw - 1 iterations whose mask nobody will read, then one that records it
-            for (uint32_t j = 1; j < kw; j++) {
-                uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
-                uint32_t mn = umin3(bx, by, bz);
-                s.sdx = bx == mn ? s.sdx + s.dx : s.sdx;
-                s.sdy = by == mn ? s.sdy + s.dy : s.sdy;
-                s.sdz = bz == mn ? s.sdz + s.dz : s.sdz;
-            }
+            for (uint32_t j = 1; j < kw; j++) dda_advance(s);
             {
                 uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
                 uint32_t mn = umin3(bx, by, bz);
-                bool k0 = bx == mn, k1 = by == mn, k2 = bz == mn;
-                mask = (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2);
+                k0 = bx == mn; k1 = by == mn; k2 = bz == mn;
                 s.sdx = k0 ? s.sdx + s.dx : s.sdx;
                 s.sdy = k1 ? s.sdy + s.dy : s.sdy;
                 s.sdz = k2 ? s.sdz + s.dz : s.sdz;
             }
-            // |dir| is 1/delta to within an ulp; for axes that cannot step (dir = 0, or 1/dir overflowed) the
-            // multiplier is 0 and sideDist stays +inf: inf - inf = NaN converts to 0 steps
-            int nx = steps_taken((s.sdx - ox) * gx), ny = steps_taken((s.sdy - oy) * gy), nz = steps_taken((s.sdz - oz) * gz);
-            s.mx += s.sx < 0 ? -nx : nx;
-            s.my += s.sy < 0 ? -ny : ny;
-            s.mz += s.sz < 0 ? -nz : nz;
+            s.mx += steps_signed(s.sdx - ox, gx);
+            s.my += steps_signed(s.sdy - oy, gy);
+            s.mz += steps_signed(s.sdz - oz, gz);
         }
         i += kw;
     }
-    finish(s, material, mask, fetches, r);
+    finish(s, material, (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2), fetches, r);
     r.dbg0 = n_outer; r.dbg1 = n_long;
 }
 
