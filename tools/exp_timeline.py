@@ -34,3 +34,6 @@ print("99th pct dur", np.percentile(dur, 99), "start of slowest 1%: mean", start
 rows = dur.mean(axis=1)
 print("mean wave duration by 8-px row group (every 8th):", [round(float(x), 1) for x in rows[::8]])
 print("mean start time by row group (every 8th):", [round(float(x), 1) for x in start.mean(axis=1)[::8]])
+if os.path.isdir("gpurun_out"):
+    np.savez_compressed("gpurun_out/timeline.npz", start=start.astype(np.float32), end=end.astype(np.float32),
+                        steps=o["steps_primary"].astype(np.int32)[:H // 8 * 8].reshape(H // 8, 8, W // 8, 8).max(axis=(1, 3)))

@@ -151,8 +151,16 @@ template <> struct OccT<false> { const uint64_t* o2; const uint64_t* o3; };
 
 __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 {
+    // normalize(-mask * rayStep) (frag:190): the vector has k = popcount(mask) components of +-1, so its length is
+    // RN(sqrt(k)) and every non-zero component is +-RN(1 / RN(sqrt(k))) -- three constants instead of a square root
+    // and three IEEE divisions (k = 0: the zero vector, canonical rule A).  A masked axis with rayStep = 0 (possible only
+    // through rule A's initial mask) changes k's meaning; that case keeps the general form.
+    const uint32_t k = __builtin_popcount(mask & 7u);
+    const float c = k == 1u ? 1.0f : (k == 2u ? __uint_as_float(0x3f3504f3u) : __uint_as_float(0x3f13cd3au));
+    const bool general = ((mask & 1u) && sx == 0) || ((mask & 2u) && sy == 0) || ((mask & 4u) && sz == 0);
     f3 n = mk3((mask & 1u) ? (float)(-sx) : 0.0f, (mask & 2u) ? (float)(-sy) : 0.0f, (mask & 4u) ? (float)(-sz) : 0.0f);
-    return normalize3(n);
+    if (general) return normalize3(n);
+    return mk3(n.x * c, n.y * c, n.z * c);
 }
 
 // traceRay, voxel_volume.frag:176-196
@@ -163,17 +171,19 @@ __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 s
     trace_int<TRAV>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
     h.material = r.material;
     h.dir = dir;
+    // values first, one assignment to h afterwards: stores to h from both sides of the branch were being merged into
+    // address-selected scratch stores (28 B of scratch per lane, which also slows the wave launch)
+    f3 pos = mk3(0.0f, 0.0f, 0.0f), nrm = mk3(0.0f, 0.0f, 0.0f);
     if (r.material != 0) {
-        h.normal = hit_normal(r.mask, r.sx, r.sy, r.sz);
+        nrm = hit_normal(r.mask, r.sx, r.sy, r.sz);
         f3 m = mk3((r.mask & 1u) ? (r.side.x - r.delta.x) : 0.0f,
                    (r.mask & 2u) ? (r.side.y - r.delta.y) : 0.0f,
                    (r.mask & 4u) ? (r.side.z - r.delta.z) : 0.0f);
         float d = len3(m);
-        h.pos = mk3(r.pos.x + d * dir.x, r.pos.y + d * dir.y, r.pos.z + d * dir.z);
-    } else {
-        h.pos = mk3(0.0f, 0.0f, 0.0f);
-        h.normal = mk3(0.0f, 0.0f, 0.0f);
+        pos = mk3(r.pos.x + d * dir.x, r.pos.y + d * dir.y, r.pos.z + d * dir.z);
     }
+    h.pos = pos;
+    h.normal = nrm;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -223,7 +233,8 @@ __device__ __forceinline__ f3 primary_dir(const GeomParams& P, int px, int py)
 }
 
 // calcAmbient + isShadowed + color + colorHit, voxel_volume.frag:205-264
-template <int TRAV, class Occ>
+// SEC = false: the host has established ao_samples == 0 and shadows == 0 (K1 MODE 1), so neither loop is compiled in.
+template <int TRAV, class Occ, bool SEC = true>
 __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit,
                         f3 reflection, uint32_t depth)
 {
@@ -232,7 +243,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
     if (hit.material == 0) return sky_color(s, hit.dir);
 
     float ambient = 0.0f;
-    if (st.ao_samples == 0) {
+    if (!SEC || st.ao_samples == 0) {
         ambient = 1.0f;
     } else {
         float sample_frac = 1.0f / (float)st.ao_samples;
@@ -253,7 +264,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
 
     bool shadowed = false;
     f3 L = mk3(st.light_dir[0], st.light_dir[1], st.light_dir[2]);
-    if (st.shadows) {
+    if (SEC && st.shadows) {
         f3 o = mk3(hit.pos.x + hit.normal.x * 0.01f, hit.pos.y + hit.normal.y * 0.01f, hit.pos.z + hit.normal.z * 0.01f);
         RayInt r;
         trace_int<TRAV>(s.vol, occ.o2, occ.o3, o, L, st.max_steps, r);
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(256) void k_primary(const GeomParams P)
         f3 col;
         if (hit) {
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
-            if (MODE == 1) col = color_hit<TRAV>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
+            if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 col = color_main_ray<TRAV>(P, occ, c, h);
                 if (f.steps_total && !(P.st.flags & 3u)) f.steps_total[i] = r.fetches + c.fetches;
