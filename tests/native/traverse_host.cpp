@@ -44,7 +44,7 @@ void* th_create(const uint8_t* vox, int W, int H, int D)
     // clearance fields: per octant three one-sided 1-D min-max passes (same definition as k_df_pass, written independently)
     {
         const int CAP = 63;
-        size_t stride = (size_t)v.n1x * v.n1y * v.n1z * 64;
+        size_t stride = df_field_bytes(W, H, D);                 // padded x-fastest fields (vrt_traverse.h df_index)
         h->df.assign(8 * stride, 0);
         std::vector<uint8_t> a((size_t)W * H * D), b((size_t)W * H * D);
         for (int o = 0; o < 8; o++) {

@@ -236,7 +236,7 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     size_t n1 = (size_t)d.n1x * d.n1y * d.n1z, n2 = (size_t)d.n2x * d.n2y * d.n2z, n3 = (size_t)d.n3x * d.n3y * d.n3z;
     size_t n2pad = (n2 + 1) & ~(size_t)1;          // 16-byte multiples for the uint4 LDS staging loop
     size_t n3pad = (n3 + 1) & ~(size_t)1;
-    size_t ndf = n1 * 64;                          // distance field, bricked: 64 B per 4^3 cell (>= nvox)
+    size_t ndf = df_field_bytes(d.W, d.H, d.D);    // one clearance field: x-fastest with a one-voxel border of zeros
     int rc = VRT_OK;
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
     SCHK(hipMalloc((void**)&s->vox, nvox));

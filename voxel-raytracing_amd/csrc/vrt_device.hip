@@ -112,9 +112,8 @@ __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox
         best = best < m ? best : m;
     }
     size_t o = i;
-    if (bricked) {                                           // final pass: 4x4x4 bricks of 64 B (vrt_traverse.h df_index)
-        size_t n1x = (size_t)(W + 3) / 4, n1y = (size_t)(H + 3) / 4;
-        o = ((size_t)(x >> 2) + ((size_t)(y >> 2) + (size_t)(z >> 2) * n1y) * n1x) * 64u + (size_t)((x & 3) | ((y & 3) << 2) | ((z & 3) << 4));
+    if (bricked) {                                           // final pass: into the zero-bordered field (vrt_traverse.h df_index)
+        o = (size_t)(x + 1) + ((size_t)(y + 1) + (size_t)(z + 1) * ((size_t)H + 2u)) * ((size_t)W + 2u);
     }
     dst[o] = (uint8_t)(best > VRT_DF_CAP ? VRT_DF_CAP : best);
 }

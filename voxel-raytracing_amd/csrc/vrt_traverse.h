@@ -138,18 +138,38 @@ VRT_HD int lookup_level(const VolumeView& v, OP o2, OP o3, int mx, int my, int m
     return 0;
 }
 
-// The distance field is stored in 4x4x4 bricks of 64 bytes (one cache line per brick): the rays of a wave are a
-// voxel or two apart, so one gather touches a couple of lines instead of one line per lane.
+// Each clearance field is a plain x-fastest volume with a one-voxel border of zeros on every side, (W+2)(H+2)(D+2)
+// bytes: voxel (x,y,z) lives at (x+1) + (y+1)*(W+2) + (z+1)*(W+2)*(H+2).  A run can carry a ray at most one voxel
+// past a wall (the fields count the outside as solid), so the traversal may read the field wherever a run ends
+// without a bounds test, and it keeps the index incrementally (two 24-bit multiply-adds per look-up).  An earlier
+// layout in 4x4x4 bricks touched fewer cache lines per gather but cost 12 VALU ops of index arithmetic plus the
+// bounds test per look-up; the kernel is bound by VALU issue, not by the vector-memory pipe.
 VRT_HD size_t df_index(const VolumeView& v, int x, int y, int z)
 {
-    size_t brick = (size_t)(x >> 2) + ((size_t)(y >> 2) + (size_t)(z >> 2) * (size_t)v.n1y) * (size_t)v.n1x;
-    return brick * 64u + cell_bit(x, y, z);
+    const size_t pw = (size_t)v.W + 2u, ph = (size_t)v.H + 2u;
+    return (size_t)(x + 1) + ((size_t)(y + 1) + (size_t)(z + 1) * ph) * pw;
 }
-// same, for fields of less than 4 GiB (the common case: 32-bit address arithmetic in the traversal loop)
-VRT_HD uint32_t df_index32(const VolumeView& v, int x, int y, int z)
+VRT_HD size_t df_field_bytes(int W, int H, int D)            // one padded field, rounded up to 256 B
 {
-    uint32_t brick = (uint32_t)(x >> 2) + ((uint32_t)(y >> 2) + (uint32_t)(z >> 2) * (uint32_t)v.n1y) * (uint32_t)v.n1x;
-    return brick * 64u + cell_bit(x, y, z);
+    size_t n = ((size_t)W + 2u) * ((size_t)H + 2u) * ((size_t)D + 2u);
+    return (n + 255u) & ~(size_t)255u;
+}
+// 32-bit incremental indexing: all eight fields below 4 GiB and a padded z-slice that fits a signed 24-bit multiply
+VRT_HD bool df_small(const VolumeView& v)
+{
+    return 8ull * v.df_stride <= 0xFFFFFFFFull && ((uint64_t)v.W + 2u) * ((uint64_t)v.H + 2u) < (1ull << 23);
+}
+template <bool SMALL> struct IndexT;
+template <> struct IndexT<true>  { typedef uint32_t type; typedef int32_t stype; };
+template <> struct IndexT<false> { typedef size_t type;   typedef long long stype; };
+// a * b for |a|, |b| < 2^23 (one v_mul_i32_i24 / v_mad_i32_i24 instead of the quarter-rate 32-bit multiply)
+VRT_HD int mul24(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
 }
 
 // ---- boxIntersection + DDA setup (frag:109-144) -------------------------------------------------------
@@ -249,16 +269,15 @@ VRT_HD int steps_signed(float dside, float g)
 }
 
 // One DDA iteration that only advances sideDist (frag:164-170 without the mapPos / mask bookkeeping).
-// Device: 8 VALU ops -- two integer mins, then per axis a v_cmpx that narrows EXEC to the lanes whose axis holds the
+// Device: 7 VALU ops -- one three-way integer min, then per axis a v_cmpx that narrows EXEC to the lanes whose axis holds the
 // minimum and a v_add_f32 that runs under it (the compiler's form is compare + select + add = 10).  EXEC is put back
 // from a scalar copy after each axis; the scalar moves issue beside other waves' vector work.
 VRT_HD void dda_advance(DdaState& s)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t txy, mn;
+    uint32_t mn;
     uint64_t saved;
-    asm volatile("v_min_u32 %[txy], %[x], %[y]\n\t"
-                 "v_min_u32 %[mn], %[txy], %[z]\n\t"
+    asm volatile("v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
                  "s_mov_b64 %[sv], exec\n\t"
                  "v_cmpx_eq_u32 %[mn], %[x]\n\t"
                  "v_add_f32 %[x], %[x], %[dx]\n\t"
@@ -266,10 +285,10 @@ VRT_HD void dda_advance(DdaState& s)
                  "v_cmpx_eq_u32 %[mn], %[y]\n\t"
                  "v_add_f32 %[y], %[y], %[dy]\n\t"
                  "s_mov_b64 exec, %[sv]\n\t"
-                 "v_cmpx_le_u32 %[z], %[txy]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[z]\n\t"
                  "v_add_f32 %[z], %[z], %[dz]\n\t"
                  "s_mov_b64 exec, %[sv]"
-                 : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [txy] "=&v"(txy), [mn] "=&v"(mn), [sv] "=&s"(saved)
+                 : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [mn] "=&v"(mn), [sv] "=&s"(saved)
                  : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz)
                  : "vcc");
 #else
@@ -338,6 +357,39 @@ VRT_HD uint32_t wave_min_u6(uint32_t k)
 #endif
 }
 
+// One vote for "is every lane finished" and "how far may the wave run": finished lanes vote VRT_VOTE_DONE, live lanes
+// their clearance (1..63); the minimum is VRT_VOTE_DONE exactly when nobody is live.
+#define VRT_VOTE_DONE 0xFFFFu
+VRT_HD uint32_t wave_min_vote(uint32_t k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(true) == ~0ull) {
+        uint32_t v = k, total;
+        asm volatile("s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_readlane_b32 %1, %0, 63\n\t"
+                     "s_nop 3"
+                     : "+v"(v), "=s"(total));
+        return total;
+    }
+    if (__ballot(k != VRT_VOTE_DONE) == 0ull) return VRT_VOTE_DONE;
+    return wave_min_u6(k < 63u ? k : 63u);
+#else
+    return k;
+#endif
+}
+
 // ---- literal traversals ---------------------------------------------------------------------------------
 
 // DF (clearance-field skip, wave-cooperative).  Profiling showed the per-iteration loops are bound by the
@@ -365,13 +417,18 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     // the mask of the latest iteration, one bool per axis: the compiler keeps each as a 64-bit lane mask in scalar
     // registers (the compare results themselves), so recording it costs no vector instructions
     bool k0 = (s.mask & 1u) != 0u, k1 = (s.mask & 2u) != 0u, k2 = (s.mask & 4u) != 0u;
-    bool done = false;
+    // a ray that starts outside the volume and misses it begins the loop at its own origin (frag:118-126) and leaves
+    // in iteration 0; every later position is inside the volume or in the one-voxel border of the fields
+    bool done = oob(v, s.mx, s.my, s.mz);
     uint32_t clear = 63u;
-    constexpr bool small = SMALL;                              // field below 4 GiB: 32-bit address arithmetic
     // clearance field of the octant the ray travels into (an axis the ray does not move along can use either sign)
     const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
-    const uint32_t octant32 = oct * (uint32_t)v.df_stride;
-    const size_t octant64 = (size_t)oct * (size_t)v.df_stride;
+    // index into the padded field, kept incrementally; IDX is 32 bits while all eight fields stay below 4 GiB
+    typedef typename IndexT<SMALL>::type IDX;
+    typedef typename IndexT<SMALL>::stype SIDX;
+    const int pw = v.W + 2;
+    const long long pwh = (long long)pw * (long long)(v.H + 2);
+    IDX idx = done ? (IDX)0 : (IDX)((size_t)oct * (size_t)v.df_stride + df_index(v, s.mx, s.my, s.mz));
     const float kInf = u2f(0x7F800000u);
     // signed steps per unit of sideDist: dir is 1/(+-delta) to within an ulp; 0 for an axis that cannot step
     const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
@@ -380,22 +437,26 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     for (;;) {
         n_outer++;
         if (!done) {
-            if (i >= maxSteps || oob(v, s.mx, s.my, s.mz)) { done = true; fetches = i; }
+            if (i >= maxSteps) { done = true; fetches = i; }
             else {
-                clear = small ? v.df[octant32 + df_index32(v, s.mx, s.my, s.mz)] : v.df[octant64 + df_index(v, s.mx, s.my, s.mz)];
+                clear = v.df[idx];
                 st_lookup(stats);
-                if (clear == 0u) {
-                    material = small ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
-                                     : voxel_at(v, s.mx, s.my, s.mz);
-                    fetches = i + 1u;
+                if (clear == 0u) {                             // solid, or the border: the ray has left the volume
+                    if (oob(v, s.mx, s.my, s.mz)) fetches = i;
+                    else {
+                        material = SMALL ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
+                                         : voxel_at(v, s.mx, s.my, s.mz);
+                        fetches = i + 1u;
+                    }
                     done = true;
                 }
             }
         }
-        if (wave_all(done)) break;
         // iterations the wave can take blind: the smallest clearance among its live lanes (the fields count the
-        // outside of the volume as solid, so a run cannot carry a lane further than one voxel past a wall)
-        uint32_t kw = wave_min_u6(done ? 63u : clear);         // >= 1: live lanes stand on empty in-bounds voxels
+        // outside of the volume as solid, so a run cannot carry a lane further than one voxel past a wall); the same
+        // vote says whether anybody is still live
+        uint32_t kw = wave_min_vote(done ? VRT_VOTE_DONE : clear);     // live lanes stand on empty in-bounds voxels: >= 1
+        if (kw == VRT_VOTE_DONE) break;
         uint32_t left = maxSteps - i;                          // i < maxSteps for every live lane
         kw = kw < left ? kw : left;
         st_jump(stats, kw > 4u ? 2 : 1);
@@ -415,9 +476,10 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
                 s.sdy = k1 ? s.sdy + s.dy : s.sdy;
                 s.sdz = k2 ? s.sdz + s.dz : s.sdz;
             }
-            s.mx += steps_signed(s.sdx - ox, gx);
-            s.my += steps_signed(s.sdy - oy, gy);
-            s.mz += steps_signed(s.sdz - oz, gz);
+            const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
+            s.mx += nx; s.my += ny; s.mz += nz;
+            idx += SMALL ? (IDX)(nx + mul24(ny, pw) + mul24(nz, (int)pwh))
+                         : (IDX)((SIDX)nx + (SIDX)ny * (SIDX)pw + (SIDX)nz * (SIDX)pwh);
         }
         i += kw;
     }
@@ -428,8 +490,9 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 template <class STATS>
 VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
-    // wave-uniform choice; the 64-bit variant is only reached by volumes whose bricked field is 4 GiB or more
-    if (8ull * v.df_stride <= 0xFFFFFFFFull) trace_df_impl<true>(v, start, dir, maxSteps, r, stats);
+    // wave-uniform choice; the 64-bit variant is only reached by volumes whose eight fields total 4 GiB or more (or
+    // whose padded z-slice does not fit the 24-bit multiply of the incremental index)
+    if (df_small(v)) trace_df_impl<true>(v, start, dir, maxSteps, r, stats);
     else trace_df_impl<false>(v, start, dir, maxSteps, r, stats);
 }
 
@@ -688,7 +751,6 @@ VRT_HD void trace_dfj(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, 
     uint32_t mask = s.mask, material = 0;
     bool done = false, hit = false;
     uint32_t clear = 63u;
-    const bool small = 8ull * v.df_stride <= 0xFFFFFFFFull;
     const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
     const size_t octant = (size_t)oct * (size_t)v.df_stride;
     const float kInf = u2f(0x7F800000u);
@@ -698,7 +760,7 @@ VRT_HD void trace_dfj(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, 
         if (!done) {
             if (lo >= maxSteps || oob(v, s.mx, s.my, s.mz)) done = true;       // certainly out of budget, or out of the volume
             else {
-                clear = small ? v.df[(uint32_t)octant + df_index32(v, s.mx, s.my, s.mz)] : v.df[octant + df_index(v, s.mx, s.my, s.mz)];
+                clear = v.df[octant + df_index(v, s.mx, s.my, s.mz)];
                 st_lookup(stats);
                 if (clear == 0u) { hit = true; done = true; }
             }
