@@ -165,6 +165,25 @@ def render(scene: OracleScene, push, params: Params, planes=None, nthreads=1, ro
     return out
 
 
+def render_band(scene: OracleScene, push, params: Params, row0, row1, planes=None, nthreads=8):
+    """Rows [row0, row1) only, split over `nthreads` Python threads (ctypes releases the GIL).  Returns (row1-row0, W, ...)
+    arrays: for full-size frames whose other rows are checked through size-independent properties."""
+    import threading
+    push = push_from(push)
+    W, H = push.screen_size[0], push.screen_size[1]
+    out, f = {}, Frame()
+    for n, dt, tail in PLANES:
+        if planes is None or n in planes:
+            out[n] = np.zeros((H, W) + tail, dtype=dt)
+            setattr(f, n, out[n].ctypes.data)
+    edges = np.linspace(row0, row1, int(nthreads) + 1).astype(int)
+    ts = [threading.Thread(target=lib().vo_render_rows, args=(C.byref(scene.c), C.byref(push), C.byref(params), C.byref(f), int(a), int(b)))
+          for a, b in zip(edges[:-1], edges[1:]) if b > a]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    return {k: v[row0:row1] for k, v in out.items()}
+
+
 def trace_ray(scene: OracleScene, start, direction, max_steps=512) -> Hit:
     h = Hit()
     s = (C.c_float * 3)(*[float(x) for x in start])

@@ -189,6 +189,30 @@ def mandelbulb(N: int = 128, power: float = 8.0, iters: int = 8, slab: int = 16)
     return v
 
 
+def sparse_bricks(N: int = 2048, brick: int = 8, fill: float = 0.015, seed: int = 5) -> np.ndarray:
+    """Config 5 stand-in (sparse2048): N^3 volume of brick^3 cells, a fraction `fill` of them occupied.  Occupied bricks
+    follow a thresholded value-noise field (trilinear over a hashed lattice of period 8 bricks) so that they cluster;
+    each occupied brick is solid with one id in 1..255 (ids 200..255 are the metallic ones of the default test palette)."""
+    nb = N // brick
+    assert nb * brick == N
+    lat = nb // 8 + 2
+    g = rand_unit(seed, lat * lat * lat, 0).reshape(lat, lat, lat).astype(np.float32)
+    t = (np.arange(nb, dtype=np.float32) + 0.5) / 8.0
+    i0 = np.floor(t).astype(np.int64); f = (t - i0).astype(np.float32)
+    def lerp_axis(a, axis):
+        lo = np.take(a, i0, axis=axis); hi = np.take(a, i0 + 1, axis=axis)
+        shape = [1, 1, 1]; shape[axis] = nb
+        w = f.reshape(shape)
+        return lo * (1 - w) + hi * w
+    field = lerp_axis(lerp_axis(lerp_axis(g, 0), 1), 2)                    # nb^3 smooth noise in [0, 1]
+    field = field + 0.15 * (rand_unit(seed, nb * nb * nb, 1).reshape(nb, nb, nb).astype(np.float32) - 0.5)
+    thr = np.quantile(field, 1.0 - fill)
+    occ = field > thr
+    ids = (1 + (rand_u32(seed, nb * nb * nb, 2) % np.uint32(255))).astype(np.uint8).reshape(nb, nb, nb)
+    cells = np.where(occ, ids, np.uint8(0))
+    return np.repeat(np.repeat(np.repeat(cells, brick, axis=0), brick, axis=1), brick, axis=2)
+
+
 def default_camera_for(N_x: int, N_y: int, N_z: int):
     """The reference default camera (8,8,-50)/yaw 90/pitch 0 (voxel_renderer.cpp:20) scaled to the volume."""
     return (N_x / 2.0, N_y / 2.0, -0.8 * N_z), 90.0, 0.0
