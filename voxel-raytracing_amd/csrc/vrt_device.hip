@@ -711,40 +711,60 @@ __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
 // R = stepWidth pixels are fetched, decoded ONCE and parked in LDS as three float4 planes (48 B per pixel), so each
 // pixel's guides are read from HBM/L2 once per pass instead of once per tap that lands on it (9x), and the 8-bit
 // decodes are not repeated per tap.  Same arithmetic on the same decoded values as k_denoise.
-template <bool PHI_INF>
+template <bool PHI_INF, bool SHIPPED>
 __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
     const int RW = 64 + 2 * R, RH = 4 + 2 * R, NP = RW * RH;
     float4* lc = lds_g; float4* ln = lds_g + NP; float4* lp = lds_g + 2 * NP;
     const int x0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
-    const int y0 = strip_row(P.sh, P.extend, r0, P.H);        // rows of one block are consecutive frame rows (checked by the launcher)
+    // rows of one block are consecutive frame rows (checked by the launcher); a single rank owns every row in order
+    const bool whole = P.sh.nranks == 1 && P.extend == 0;
+    const int y0 = whole ? (r0 < P.H ? r0 : -1) : strip_row(P.sh, P.extend, r0, P.H);
     if (y0 < 0) return;
-    for (int t = threadIdx.x; t < NP; t += 256) {
-        int lx = t % RW, ly = t / RW;
-        Guides g;
-        texel_guides(P, x0 - R + lx, y0 - R + ly, g);         // clamp-to-edge inside
-        lc[t] = make_float4(g.c[0], g.c[1], g.c[2], g.c[3]);
-        ln[t] = make_float4(g.n[0], g.n[1], g.n[2], g.n[3]);
-        lp[t] = make_float4(g.p[0], g.p[1], g.p[2], g.p[3]);
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    // staging: thread (lx, ly) loads columns lx and (for lx < 2R) 64 + lx of rows ly, ly + 4, ... of the haloed tile
+    {
+        const int ncol = lx < 2 * R ? 2 : 1;
+        for (int k = 0; k < ncol; k++) {
+            const int cx = k == 0 ? lx : 64 + lx;
+            int x = x0 - R + cx;
+            x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+            for (int cy = ly; cy < RH; cy += 4) {
+                int y = y0 - R + cy;
+                y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+                const size_t i = (size_t)y * (size_t)P.W + (size_t)x;
+                const int t = cy * RW + cx;
+                const uchar4 c = reinterpret_cast<const uchar4*>(P.color_in)[i];
+                lc[t] = make_float4(decode_unorm8(c.x), decode_unorm8(c.y), decode_unorm8(c.z), decode_unorm8(c.w));
+                if (!PHI_INF) {                               // pass 0 weighs every tap 1: only the colour is ever read
+                    const char4 n = reinterpret_cast<const char4*>(P.normal)[i];
+                    ln[t] = make_float4(decode_snorm8(n.x), decode_snorm8(n.y), decode_snorm8(n.z), decode_snorm8(n.w));
+                    lp[t] = reinterpret_cast<const float4*>(P.position)[i];
+                }
+            }
+        }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int px = x0 + lx, py = y0 + ly;
     if (px >= P.W || py >= P.H) return;
-    if (strip_row(P.sh, P.extend, r0 + ly, P.H) != py) return;   // past the end of the strip / frame
+    if (!whole && strip_row(P.sh, P.extend, r0 + ly, P.H) != py) return;   // past the end of the strip / frame
 
-    const bool shipped = P.mode == VRT_DENOISE_AS_SHIPPED;
-    const int ntaps = shipped ? 3 : 9;
+    constexpr int ntaps = SHIPPED ? 3 : 9;
     const float sw = P.step_width, sw2 = sw * sw;
     const int c0 = (ly + R) * RW + (lx + R);
-    const float4 sc = lc[c0], sn = ln[c0], sp = lp[c0];
+    const float4 sc = lc[c0], sn = PHI_INF ? sc : ln[c0], sp = PHI_INF ? sc : lp[c0];
     const float s_c[4] = {sc.x, sc.y, sc.z, sc.w}, s_n[4] = {sn.x, sn.y, sn.z, sn.w}, s_p[4] = {sp.x, sp.y, sp.z, sp.w};
     float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float total = 0.0f;
+    const int rowoff = R * RW;
+    // pass 0 unrolls into nine LDS reads and 72 multiply-adds; the weighted taps stay a loop (unrolled they need 72
+    // VGPRs and 14 KB of code, and measured 7 % slower)
+    constexpr int kUnroll = PHI_INF ? 9 : 1;
+#pragma unroll kUnroll
     for (int i = 0; i < ntaps; i++) {
         int tx, ty; float kern;
-        if (shipped) {
+        if (SHIPPED) {
             tx = i == 0 ? -1 : (i == 1 ? 1 : 0); ty = i == 2 ? 0 : -1;
             kern = i == 1 ? kGauss0 : kGauss2;
         } else {
@@ -752,7 +772,7 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
             int r2 = tx * tx + ty * ty;
             kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2);
         }
-        const int ci = c0 + ty * R * RW + tx * R;
+        const int ci = c0 + ty * rowoff + tx * R;
         const float4 oc = lc[ci];
         const float o_c[4] = {oc.x, oc.y, oc.z, oc.w};
         float w = 1.0f;
@@ -774,8 +794,25 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
         total += w * kern;
     }
     uchar4 out;
-    out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
-    out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
+    if (PHI_INF) {
+        // sums are 0 or >= 1/255 * 0.77 and total is the fixed sum of the tap weights (3.3 .. 7.7): no operand or
+        // quotient of these four divisions is anywhere near the range where the IEEE sequence rescales, so its core --
+        // reciprocal refined once, then two residual corrections per quotient -- can share the reciprocal (23 VALU
+        // ops instead of 40) and still round every quotient correctly
+        const float r0 = __builtin_amdgcn_rcpf(total);
+        const float r = __builtin_fmaf(__builtin_fmaf(-total, r0, 1.0f), r0, r0);
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float q0 = sum[k] * r;
+            float q1 = __builtin_fmaf(__builtin_fmaf(-total, q0, sum[k]), r, q0);
+            q[k] = __builtin_fmaf(__builtin_fmaf(-total, q1, sum[k]), r, q1);
+        }
+        out.x = unorm8(q[0]); out.y = unorm8(q[1]); out.z = unorm8(q[2]); out.w = unorm8(q[3]);
+    } else {
+        out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
+        out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
+    }
     reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
 }
 
@@ -792,9 +829,12 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     int R = (int)sw;
     bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
     if (tiled) {
-        size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * 48;
-        if (inf) hipLaunchKernelGGL(k_denoise_lds<true>, grid, block, lds, s, p, R);
-        else     hipLaunchKernelGGL(k_denoise_lds<false>, grid, block, lds, s, p, R);
+        size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * (inf ? 16 : 48);   // pass 0 stages the colour plane only
+        const bool shipped = p.mode == VRT_DENOISE_AS_SHIPPED;
+        if (inf) { if (shipped) hipLaunchKernelGGL((k_denoise_lds<true, true>), grid, block, lds, s, p, R);
+                   else         hipLaunchKernelGGL((k_denoise_lds<true, false>), grid, block, lds, s, p, R); }
+        else     { if (shipped) hipLaunchKernelGGL((k_denoise_lds<false, true>), grid, block, lds, s, p, R);
+                   else         hipLaunchKernelGGL((k_denoise_lds<false, false>), grid, block, lds, s, p, R); }
     } else {
         if (inf) hipLaunchKernelGGL(k_denoise<true>, grid, block, 0, s, p);
         else     hipLaunchKernelGGL(k_denoise<false>, grid, block, 0, s, p);
