@@ -94,7 +94,7 @@ hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_
 
 // src == nullptr: first pass, the field is (vox != 0 ? 0 : INF).
 __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox, const uint8_t* __restrict__ src,
-                                                 uint8_t* __restrict__ dst, int W, int H, int D, int axis, int dir, int bricked)
+                                                 uint8_t* __restrict__ dst, int W, int H, int D, int axis, int dir, int padded)
 {
     size_t n = (size_t)W * H * D;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,13 +112,13 @@ __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox
         best = best < m ? best : m;
     }
     size_t o = i;
-    if (bricked) {                                           // final pass: into the zero-bordered field (vrt_traverse.h df_index)
+    if (padded) {                                            // final pass: into the zero-bordered field (vrt_traverse.h df_index)
         o = (size_t)(x + 1) + ((size_t)(y + 1) + (size_t)(z + 1) * ((size_t)H + 2u)) * ((size_t)W + 2u);
     }
     dst[o] = (uint8_t)(best > VRT_DF_CAP ? VRT_DF_CAP : best);
 }
 
-// df: 8 * stride bytes (stride = bricked size of one field, >= W*H*D); tmp0/tmp1: W*H*D bytes each
+// df: 8 * stride bytes (stride = df_field_bytes: one zero-bordered field); tmp0/tmp1: W*H*D bytes each
 hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s)
 {
     size_t n = (size_t)W * H * D;

@@ -15,8 +15,8 @@ namespace vrt {
 //   vol.occ1  one u64 per 4^3 voxels  : bit (x&3) | (y&3)<<2 | (z&3)<<4 set <=> voxel != 0      [n1x*n1y*n1z]
 //   vol.occ2  one u64 per 16^3 voxels : bit over the 4x4x4 occ1 words, set <=> word != 0        [n2x*n2y*n2z]
 //   vol.occ3  one u64 per 64^3 voxels : same over occ2                                           [n3x*n3y*n3z]
-//   vol.df    8 octant clearance fields of n1x*n1y*n1z*64 bytes each (4^3 bricks): 0 = solid, else min(63, side of the
-//             largest empty cube cornered at the voxel and extending towards the octant's signs)
+//   vol.df    8 octant clearance fields of (W+2)(H+2)(D+2) bytes each (x-fastest, one-voxel border of zeros): 0 = solid,
+//             else min(63, side of the largest empty cube cornered at the voxel and extending towards the octant's signs)
 struct DevScene {
     VolumeView vol;
     const vrt_material* palette;

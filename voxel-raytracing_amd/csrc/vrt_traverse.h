@@ -49,7 +49,7 @@ struct VolumeView {
     const uint64_t* occ1;    // per 4^3 voxels, bit (x&3)|(y&3)<<2|(z&3)<<4
     const uint64_t* occ2;    // per 16^3
     const uint64_t* occ3;    // per 64^3
-    const uint8_t*  df;      // 8 octant clearance fields, each in 64-byte bricks of 4^3 voxels (df_index): field o
+    const uint8_t*  df;      // 8 octant clearance fields, each x-fastest with a one-voxel border of zeros (df_index): field o
                              // (bit0: +x, bit1: +y, bit2: +z) holds per voxel 0 = solid, else min(63, side of the largest
                              // empty cube that has this voxel as its corner and extends towards the octant's signs;
                              // outside the volume counts as solid)
