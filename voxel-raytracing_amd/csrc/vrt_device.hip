@@ -383,7 +383,7 @@ template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomPara
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
 template <int TRAV, bool OCC_LDS, int MODE>
-__global__ __launch_bounds__(256) void k_primary(const GeomParams P)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_primary(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     const uint64_t t_begin = (P.st.flags & 2u) ? wall_clock64() : 0ull;      // diagnostic timeline (100 MHz)
