@@ -248,3 +248,25 @@ def test_argument_validation(vrt, engine):
     st.traceSettings.maxReflections = 9
     with pytest.raises(vrt.VrtError, match="max_bounces"):
         stage.record(camera_push(vrt, (8, 8, 8), (16, 16)))
+
+
+@pytest.mark.parametrize("res", [(1, 1), (7, 5), (9, 17), (65, 3), (8, 8), (130, 1)])
+def test_tiny_and_ragged_frames(vrt, oracle, engine, res):
+    """Frames smaller than a tile, one pixel wide / high, and sizes that leave partial tiles on both edges: geometry and
+    the denoiser (whose LDS tile then hangs over the frame on every side) against the oracle."""
+    vol = vrt.synthetic.floating_cubes(32, seed=8, count=40)
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    st = vrt.VoxelRenderSettings(targetResolution=res)
+    st.fsrSetttings.enable = False
+    st.occlusionSettings.numSamples = 2
+    st.denoiserSettings.iterations = 3
+    push = camera_push(vrt, (32, 32, 32), res, frame=1)
+    got, exp = _render_both(vrt, oracle, engine, gs, osn, st, push)
+    assert not compare_planes(got, exp, GB + DBG)
+    stage = vrt.GeometryStage(engine, st, gs)
+    gb = stage.record(push)
+    den = vrt.DenoiserStage(engine, st).record(gb.color, gb.normal, gb.position)
+    engine.synchronize()
+    e = oracle.denoise(exp["color8"], exp["normal8"], exp["position"], iterations=3)
+    assert (den.cpu().numpy() == e).all()
