@@ -415,10 +415,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (hit) depth = len3(mk3(h.pos.x - start.x, h.pos.y - start.y, h.pos.z - start.z));
     if (f.depth) f.depth[i] = depth;
     if (f.motion) reinterpret_cast<float2*>(f.motion)[i] = make_float2(0.0f, 0.0f);
-    if (f.mask8) f.mask8[i] = unorm8(hit ? 0.9f : 0.0f);
+    if (f.mask8) f.mask8[i] = hit ? (uint8_t)230 : (uint8_t)0;          // unorm8(0.9f) = 230 (tests/test_oracle_kat.py), unorm8(0) = 0
     if (f.position) reinterpret_cast<float4*>(f.position)[i] = make_float4(h.pos.x, h.pos.y, h.pos.z, 0.0f);
     if (f.normal8) {
-        char4 n; n.x = snorm8(h.normal.x); n.y = snorm8(h.normal.y); n.z = snorm8(h.normal.z); n.w = 0;
+        char4 n = make_char4(0, 0, 0, 0);                                   // miss: normal = 0; a wave without a hit skips the conversions
+        if (hit) { n.x = snorm8(h.normal.x); n.y = snorm8(h.normal.y); n.z = snorm8(h.normal.z); }
         reinterpret_cast<char4*>(f.normal8)[i] = n;
     }
     if (f.hit_id) f.hit_id[i] = (uint8_t)h.material;

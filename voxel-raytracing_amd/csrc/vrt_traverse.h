@@ -181,9 +181,12 @@ struct DdaState {
     float dx, dy, dz;         // deltaDist
     int sx, sy, sz;           // rayStep
     uint32_t mask;            // rule A initial mask
+    float ivx, ivy, ivz;      // 1 / dir (dda_entry -> dda_rest)
 };
 
-VRT_HD void dda_setup(const VolumeView& v, f3 start, f3 dir, DdaState& s)
+// boxIntersection (frag:109-125) and the first mapPos (frag:135): everything needed to know whether the march can
+// leave the volume in iteration 0.
+VRT_HD void dda_entry(const VolumeView& v, f3 start, f3 dir, DdaState& s)
 {
     float ivx = 1.0f / dir.x, ivy = 1.0f / dir.y, ivz = 1.0f / dir.z;
     float t1x = (-start.x) * ivx, t2x = ((float)v.W - start.x) * ivx;
@@ -201,12 +204,24 @@ VRT_HD void dda_setup(const VolumeView& v, f3 start, f3 dir, DdaState& s)
         s.mask = (uint32_t)(tnx == tmin) | ((uint32_t)(tny == tmin) << 1) | ((uint32_t)(tnz == tmin) << 2);
     }
     s.mx = (int)floorf(s.p.x); s.my = (int)floorf(s.p.y); s.mz = (int)floorf(s.p.z);
-    s.dx = fabsf(ivx); s.dy = fabsf(ivy); s.dz = fabsf(ivz);
+    s.ivx = ivx; s.ivy = ivy; s.ivz = ivz;
+}
+
+// deltaDist, rayStep, sideDist (frag:136-144)
+VRT_HD void dda_rest(f3 dir, DdaState& s)
+{
+    s.dx = fabsf(s.ivx); s.dy = fabsf(s.ivy); s.dz = fabsf(s.ivz);
     float gx = fsign(dir.x), gy = fsign(dir.y), gz = fsign(dir.z);
     s.sx = (int)gx; s.sy = (int)gy; s.sz = (int)gz;
     s.sdx = ((gx * ((float)s.mx - s.p.x) + gx * 0.5f) + 0.5f) * s.dx;
     s.sdy = ((gy * ((float)s.my - s.p.y) + gy * 0.5f) + 0.5f) * s.dy;
     s.sdz = ((gz * ((float)s.mz - s.p.z) + gz * 0.5f) + 0.5f) * s.dz;
+}
+
+VRT_HD void dda_setup(const VolumeView& v, f3 start, f3 dir, DdaState& s)
+{
+    dda_entry(v, start, dir, s);
+    dda_rest(dir, s);
 }
 
 VRT_HD bool oob(const VolumeView& v, int mx, int my, int mz)
@@ -407,7 +422,17 @@ template <bool SMALL, class STATS>
 VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
-    dda_setup(v, start, dir, s);
+    dda_entry(v, start, dir, s);
+    // A ray that starts outside the volume and misses it begins the loop at its own origin (frag:118-126) and leaves in
+    // iteration 0.  When that is every lane of the wave -- the sky tiles of a frame -- the rest of the set-up, the
+    // look-up and the vote have nothing to decide.
+    if (wave_all(oob(v, s.mx, s.my, s.mz))) {
+        s.dx = s.dy = s.dz = 0.0f; s.sdx = s.sdy = s.sdz = 0.0f; s.sx = s.sy = s.sz = 0;
+        finish(s, 0u, s.mask, 0u, r);
+        r.dbg0 = 1u; r.dbg1 = 0u;
+        return;
+    }
+    dda_rest(dir, s);
 #if defined(__HIP_DEVICE_COMPILE__)
     // deltaDist = |1/dir|: keep the three values in registers of their own (otherwise the |.| is rematerialised as
     // an extra VALU op in every iteration of the stepping loop, whose asm operands cannot take source modifiers)
