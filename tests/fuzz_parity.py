@@ -1,9 +1,9 @@
 """Randomised parity sweep: HIP path (C-ABI) vs the CPU oracle on random scenes, cameras and settings.
-   python tools/fuzz_parity.py [cases] [seed]      -- prints one line per failing case and a summary; exit code 1 on mismatch.
+   python tests/fuzz_parity.py [cases] [seed]      -- prints one line per failing case and a summary; exit code 1 on mismatch.
 Test infrastructure (uses oracle/); not part of the product."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import voxel_raytracing_amd as vrt
 from oracle import oracle

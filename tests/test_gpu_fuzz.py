@@ -1,4 +1,4 @@
-"""Randomised parity sweep (tools/fuzz_parity.py): random scenes (cubic and non-cubic, empty to dense), cameras (outside,
+"""Randomised parity sweep (tests/fuzz_parity.py): random scenes (cubic and non-cubic, empty to dense), cameras (outside,
 inside, on lattice points, missing the volume), every traversal mode, split / megakernel, budgets from 0 to 2000 steps,
 jitter, random light, denoiser passes / step widths / UBO modes -- all planes bit-exact against the oracle."""
 import os
@@ -7,7 +7,6 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
 def test_fuzz_parity(engine):
