@@ -270,3 +270,18 @@ def test_tiny_and_ragged_frames(vrt, oracle, engine, res):
     engine.synchronize()
     e = oracle.denoise(exp["color8"], exp["normal8"], exp["position"], iterations=3)
     assert (den.cpu().numpy() == e).all()
+
+
+def test_host_pointers_are_refused(vrt, engine):
+    """A host pointer in vrt_frame must come back as an error code, not as a GPU fault."""
+    import ctypes as C
+    vol = vrt.synthetic.floating_cubes(16, seed=1, count=5)
+    sc = vrt.VoxelScene.from_dense(engine, vol, vrt.synthetic.default_palette())
+    st = vrt.VoxelRenderSettings.primary_only((32, 16))
+    push = camera_push(vrt, (16, 16, 16), (32, 16))
+    host = np.zeros((16, 32, 4), np.uint8)
+    fr = vrt._capi.Frame()
+    fr.color8 = host.ctypes.data
+    stc = st.to_c()
+    rc = vrt.lib().vrt_render_geometry(engine.ctx, sc.handle, C.byref(push), C.byref(stc), C.byref(fr), None)
+    assert rc != 0 and b"not device memory" in vrt.lib().vrt_last_error()

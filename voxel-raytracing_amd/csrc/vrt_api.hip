@@ -45,6 +45,7 @@ struct vrt_ctx {
     uint4* records = nullptr;
     uint32_t* hit_list = nullptr;     // [records_px] + 1 counter word at the end
     size_t records_px = 0;
+    uint64_t checked_ptrs[2] = {0, 0};   // digests of the image pointers last verified to be device memory (geometry, denoiser)
 };
 
 struct vrt_scene {
@@ -448,6 +449,26 @@ int make_shard(const vrt_shard* sh, int H, ShardMap& m, int* max_local_strips)
     return VRT_OK;
 }
 
+
+// Image planes must be device memory: a host pointer handed to a kernel is a GPU fault, not an error code.  The pointer
+// set of a render loop repeats from call to call, so the (comparatively slow) attribute query runs only when it changes.
+static int check_device_ptrs(vrt_ctx* c, int slot, const void* const* ptrs, int n, const char* what)
+{
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+    for (int i = 0; i < n; i++) { h ^= (uint64_t)(uintptr_t)ptrs[i]; h *= 0x100000001b3ull; }
+    if (h == c->checked_ptrs[slot]) return VRT_OK;
+    for (int i = 0; i < n; i++) {
+        if (!ptrs[i]) continue;
+        hipPointerAttribute_t a;
+        hipError_t e = hipPointerGetAttributes(&a, ptrs[i]);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(VRT_ERR_INVALID, std::string(what) + ": image pointer is not device memory (host pointer?)"); }
+        if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged)
+            return fail(VRT_ERR_INVALID, std::string(what) + ": image pointer is not device memory");
+    }
+    c->checked_ptrs[slot] = h;
+    return VRT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -475,6 +496,12 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     if (st->traversal == VRT_TRAVERSAL_DENSE && (uint64_t)s->d.vol.W * (uint64_t)s->d.vol.H * (uint64_t)s->d.vol.D > 0xFFFFFFFFull)
         return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: VRT_TRAVERSAL_DENSE indexes voxels in 32 bits (volumes below 4 GiB)");
     HIPCHK(hipSetDevice(c->device));
+    {
+        const void* ptrs[13] = {frame->color8, frame->depth, frame->motion, frame->mask8, frame->position, frame->normal8, frame->color_f,
+                                frame->hit_id, frame->hit_voxel, frame->hit_mask, frame->steps_primary, frame->steps_total, frame->rays_total};
+        int prc = check_device_ptrs(c, 0, ptrs, 13, "vrt_render_geometry");
+        if (prc != VRT_OK) return prc;
+    }
 
     GeomParams p;
     memset(&p, 0, sizeof p);
@@ -555,6 +582,11 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
     if (!(ds->step_width >= 0.0f)) return fail(VRT_ERR_INVALID, "vrt_denoise: step_width must be >= 0");
     if (W <= 0 || H <= 0) return fail(VRT_ERR_INVALID, "vrt_denoise: bad size");
     HIPCHK(hipSetDevice(c->device));
+    {
+        const void* ptrs[5] = {color_in, normal8, position, target0, target1};
+        int prc = check_device_ptrs(c, 1, ptrs, 5, "vrt_denoise");
+        if (prc != VRT_OK) return prc;
+    }
     DenoiseParams p;
     memset(&p, 0, sizeof p);
     int rc = make_shard(shard, H, p.sh, nullptr);

@@ -219,16 +219,16 @@ class Engine:
     def __init__(self, device: int = 0, use_torch_stream: bool = True):
         l = lib()
         self.device = int(device)
-        if use_torch_stream:
-            _torch().cuda.init()                 # torch's HIP runtime first (see _capi.lib)
+        torch = _torch()
+        torch.cuda.init()                        # torch's HIP runtime first (see _capi.lib)
         self._ctx = C.c_void_p()
         check(l.vrt_ctx_create(self.device, C.byref(self._ctx)))
-        self.torch_device = None
+        self.torch_device = torch.device("cuda", self.device)      # where the stages allocate their images
         if use_torch_stream:
-            torch = _torch()
-            self.torch_device = torch.device("cuda", self.device)
             stream = torch.cuda.current_stream(self.torch_device)
             check(l.vrt_ctx_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)))
+        # use_torch_stream=False: the context keeps its own non-blocking stream (a second frame in flight); torch
+        # allocations and fills on torch's stream must then be synchronised by the caller before the first use
 
     @property
     def ctx(self):
