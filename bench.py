@@ -5,11 +5,13 @@ algorithmic GB/s of the primary-ray DDA kernel against the MI355X HBM peak.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: a batch of N frames (N = number
-of GPUs; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips that are
-dealt round-robin to the N ranks, traced by K1 (primary-ray DDA + G-buffer), packed, and gathered to rank 0
-with ONE RCCL gather per step.  Per-GPU work per step is therefore one frame's worth of rays at every N
-("weak" scaling); value = total primary rays of all ranks / wall time.  At N = 1 there is no collective.
+A "step" is one pass of the hot path over one batch of synthetic input: a batch of N x F frames (N = number of GPUs,
+F = --frames-per-gpu, default 4; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips
+that are dealt round-robin to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch per
+8 frames (vrt_render_geometry_batch: the next frame's tiles are dispatched while the previous frame drains), packs
+them with one launch, and the batch is gathered to rank 0 with ONE RCCL gather per step and assembled there with one
+launch per 64 (frame, source) pairs.  Per-GPU work per step is therefore F frames' worth of rays at every N ("weak"
+scaling); value = total primary rays of all ranks / wall time.  At N = 1 there is no collective and no copy.
 
 Workload = BASELINE.json configs[1]: treehouse stand-in (synthetic:treehouse(seed=2), 256^3 -- the real
 treehouse.vox is a git-LFS pointer in the reference checkout), 1920x1080, primary rays only.
@@ -43,6 +45,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
+    ap.add_argument("--frames-per-gpu", type=int, default=4, help="frames of the batch per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -72,30 +75,17 @@ def main():
     st = vrt.VoxelRenderSettings.primary_only((W, H), trav)
     renderer = vrt.VoxelRenderer(engine, st, scene)
     pos0, yaw, pitch = vrt.synthetic.default_camera_for(NV, NV, NV)
-    poses = [np.array([pos0[0] + 1.5 * f, pos0[1] + 0.5 * f, pos0[2] + 2.0 * f], np.float32) for f in range(world)]
-    sf = vrt.distributed.ShardedFrame(renderer, rank, world)
+    F = world * max(1, args.frames_per_gpu)                   # frames of a batch
+    poses = [np.array([pos0[0] + 1.5 * f, pos0[1] + 0.5 * f, pos0[2] + 2.0 * f], np.float32) for f in range(F)]
     pushes = []
-    for f in range(world):                                    # camera + push constants per pose, marshalled once
+    for f in range(F):                                        # camera + push constants per pose, marshalled once
         renderer.camera.position = poses[f]
         pushes.append(renderer.push_constants())
-    launch = renderer._geometryStage.prepare(sf.shard)        # GeometryStage::record with pre-marshalled settings
-    batch = torch.zeros((world,) + tuple(sf.packed.shape), dtype=torch.uint8, device=engine.torch_device) if world > 1 else None
-    finals = [torch.zeros((H, W, 4), dtype=torch.uint8, device=engine.torch_device) for _ in range(world)] if (world > 1 and rank == 0) else None
-    import ctypes as C
-    lib = vrt.lib()
+    sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world)
+    launches_per_step = (F + 7) // 8                          # K1 launches per rank and step
 
     def step():
-        for f in range(world):
-            color = launch(pushes[f]).color                   # K1 on this rank's strips of frame f
-            if world > 1:
-                vrt._capi.check(lib.vrt_pack_rows(engine.ctx, color.data_ptr(), batch[f].data_ptr(), W, H, 4, C.byref(sf.shard)))
-        if world > 1:
-            bufs = vrt.distributed.gather_packed(batch, 0)    # ONE RCCL gather per step (all N frames' strips)
-            if rank == 0:
-                for src, b in enumerate(bufs):
-                    sh = vrt._capi.Shard(src, world, sf.strip_rows)
-                    for f in range(world):
-                        vrt._capi.check(lib.vrt_unpack_rows(engine.ctx, b[f].data_ptr(), finals[f].data_ptr(), W, H, 4, C.byref(sh)))
+        sb.step(pushes)       # K1 over this rank's strips of the F frames (+ pack, ONE RCCL gather, unpack on rank 0)
 
     def barrier():
         if world > 1:
@@ -109,7 +99,8 @@ def main():
     t0 = time.perf_counter()
     # HIP events on the launch stream (the context runs on torch's current stream), one every EV_EVERY steps so
     # that the event packets themselves do not pace the queue; with N = 1 and the fused primary-only kernel a
-    # step is exactly one k_primary launch, so (event span) / (launches in the span) is its average duration.
+    # step is exactly launches_per_step k_primary launches and nothing else, so (event span) / (launches in the
+    # span) is the kernel's average duration.
     EV_EVERY = 10
     marks = [torch.cuda.Event(enable_timing=True)]
     marks[0].record()
@@ -124,23 +115,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    rays_per_step = world * W * H
+    rays_per_step = F * W * H
     value = rays_per_step * args.steps / dt / 1e6
-    kern_ms = float(marks[0].elapsed_time(marks[-1])) / (args.steps * world)   # per launch (world launches per step)
+    kern_ms = float(marks[0].elapsed_time(marks[-1])) / (args.steps * launches_per_step)   # per K1 launch
 
     out = None
     if rank == 0:
         # ---- algorithmic bytes of one K1 launch: S fetches (1 B each) + W*H*B_out ----
         engine.set_timing(True)
         st_dbg = vrt.VoxelRenderSettings.primary_only((W, H), vrt.TRAVERSAL_BITMASK)
-        renderer.camera.position = poses[0]
         stage = vrt.GeometryStage(engine, st_dbg, scene, debug_planes=True)
-        gb = stage.record(renderer.push_constants())
-        engine.synchronize()
-        S_frame = int(gb.steps_primary.to(torch.int64).sum().item())
-        hit_frac = float((gb.hit_id != 0).float().mean().item())
-        launches_share = 1.0 / world                           # a launch covers this rank's strips of one frame
-        b_alg = (S_frame + W * H * B_OUT) * launches_share
+        S_frames, hit_frac = [], []
+        for f in range(min(F, 8)):                            # the frames of the first launch of a step
+            gb = stage.record(pushes[f])
+            engine.synchronize()
+            S_frames.append(int(gb.steps_primary.to(torch.int64).sum().item()))
+            hit_frac.append(float((gb.hit_id != 0).float().mean().item()))
+            if f == 0:
+                hit0 = gb.hit_id.cpu().numpy()
+        S_frame = S_frames[0]
+        frames_per_launch = min(F, 8)
+        # a launch covers this rank's strips (1 / world of the rows) of frames_per_launch frames
+        b_alg = (sum(S_frames) + frames_per_launch * W * H * B_OUT) / world
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         tm = engine.last_timings()
         # HBM bytes per K1 launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
@@ -152,6 +148,8 @@ def main():
         if pm and world == 1 and (W, H, NV) == (1920, 1080, 256) and args.traversal in ("AUTO", "DF"):
             try:
                 pj = json.load(open(pm[-1]))
+                if int(pj.get("frames_per_launch", 1)) != frames_per_launch:
+                    raise ValueError("PMC summary was collected at another batch size")
                 traffic = int(pj["hbm_bytes_per_launch"]["total_guide_rule"])
                 traffic_src = os.path.relpath(pm[-1], ROOT)
             except Exception:
@@ -159,18 +157,17 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "k_primary", "kernel_ms": round(kern_ms, 5),
-                    "algorithmic_bytes_per_launch": int(b_alg), "dda_steps_per_frame": S_frame,
-                    "steps_per_ray": round(S_frame / (W * H), 2)}
+                    "frames_per_launch": frames_per_launch, "algorithmic_bytes_per_launch": int(b_alg),
+                    "dda_steps_per_frame": S_frame, "steps_per_ray": round(S_frame / (W * H), 2)}
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import oracle                          # checker / CPU baseline only
             osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
             ncores = min(os.cpu_count() or 1, 16)
-            push = renderer.push_constants()
             c0 = time.perf_counter()
-            exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=["hit_id", "steps_primary"], nthreads=ncores)
+            exp = oracle.render(osn, pushes[0], oracle.params_from(st.to_c()), planes=["hit_id", "steps_primary"], nthreads=ncores)
             cdt = time.perf_counter() - c0
-            same = bool((exp["hit_id"] == gb.hit_id.cpu().numpy()).all()) and int(exp["steps_primary"].sum()) == S_frame
+            same = bool((exp["hit_id"] == hit0).all()) and int(exp["steps_primary"].sum()) == S_frame
             cpu = {"value": round(W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
                    "sample": f"one full {W}x{H} frame of the same workload (pose 0), scalar C oracle, rows interleaved over {ncores} threads",
                    "hit_ids_match_gpu": same}
@@ -179,9 +176,10 @@ def main():
                "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"synthetic:treehouse(seed=2) {NV}^3 stand-in for treehouse.vox, {W}x{H}, primary rays only "
-                                      f"(BASELINE configs[1]); {world} frame(s)/step, 16-row strips round-robin over {world} GPU(s)"
+                                      f"(BASELINE configs[1]); {F} frame(s)/step ({F // world} per GPU, consecutive poses, one K1 launch per 8), "
+                                      f"16-row strips round-robin over {world} GPU(s)"
                                       + (", one RCCL gather/step" if world > 1 else ""),
-                          "traversal": args.traversal, "hit_fraction": round(hit_frac, 4), "bytes_out_per_px": B_OUT,
+                          "traversal": args.traversal, "frames_per_step": F, "hit_fraction": round(hit_frac[0], 4), "bytes_out_per_px": B_OUT,
                           "device": engine.device_info()[0]},
                "roofline": roofline, "cpu_baseline": cpu}
         log(f"timings of last call: {tm}")

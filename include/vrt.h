@@ -187,6 +187,14 @@ void vrt_settings_default(vrt_settings* s);
 int  vrt_render_geometry(vrt_ctx* ctx, const vrt_scene* sc, const vrt_push* push,
                          const vrt_settings* settings, const vrt_frame* frame, const vrt_shard* shard);
 
+/* The same for n frames of one scene, one screen size and one set of settings -- consecutive camera poses of an
+ * animation (App::run's frame loop, source/app.cpp:18-27, rendered offline), or the frames of a multi-GPU batch --
+ * in ONE launch per 8 frames: the tiles of frame f+1 are dispatched while frame f drains, so the tail of a frame
+ * (tens of microseconds during which most of the GPU idles) is paid once per launch instead of once per frame.
+ * pushes[n], frames[n]; every frame needs its own output planes.  Results are identical to n single calls. */
+int  vrt_render_geometry_batch(vrt_ctx* ctx, const vrt_scene* sc, int32_t n, const vrt_push* pushes,
+                               const vrt_settings* settings, const vrt_frame* frames, const vrt_shard* shard);
+
 /* ---- denoiser stage -------------------------------------------------------------------------- */
 #define VRT_DENOISE_CANONICAL  0  /* the intended 9-tap a-trous filter                               */
 #define VRT_DENOISE_AS_SHIPPED 1  /* the std140-aliased 3-tap filter the shipped UBO upload produces  */
@@ -223,6 +231,12 @@ int  vrt_pack_rows(vrt_ctx* ctx, const void* full, void* packed, int32_t W, int3
                    int32_t bytes_per_px, const vrt_shard* shard);
 int  vrt_unpack_rows(vrt_ctx* ctx, const void* packed, void* full, int32_t W, int32_t H,
                      int32_t bytes_per_px, const vrt_shard* shard);
+/* The same for n images in one launch per 64 images (host arrays of n device pointers): the frames of a batch on a
+ * rank (one shard for all), and at the root of the gather frames x source ranks (shards[n], one per image). */
+int  vrt_pack_rows_batch(vrt_ctx* ctx, int32_t n, const void* const* full, void* const* packed, int32_t W, int32_t H,
+                         int32_t bytes_per_px, const vrt_shard* shard);
+int  vrt_unpack_rows_batch(vrt_ctx* ctx, int32_t n, const void* const* packed, void* const* full, int32_t W, int32_t H,
+                           int32_t bytes_per_px, const vrt_shard* shards);
 /* Pack / unpack the halo rows exchanged with the ring neighbours before a sharded denoise:
  * dir = -1: the first `halo` rows of every owned strip (sent to the rank owning the strip above),
  * dir = +1: the last `halo` rows of every owned strip (sent to the rank owning the strip below).

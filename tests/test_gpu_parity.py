@@ -285,3 +285,35 @@ def test_host_pointers_are_refused(vrt, engine):
     stc = st.to_c()
     rc = vrt.lib().vrt_render_geometry(engine.ctx, sc.handle, C.byref(push), C.byref(stc), C.byref(fr), None)
     assert rc != 0 and b"not device memory" in vrt.lib().vrt_last_error()
+
+
+@pytest.mark.parametrize("mode", ["primary_only", "default", "split"])
+def test_batch_of_frames_equals_single_calls(vrt, oracle, engine, mode):
+    """vrt_render_geometry_batch: 11 poses (two launches: 8 + 3) must give exactly the planes of 11 single calls; three of
+    them are also checked against the oracle.  Sharded: the strips of a simulated rank only."""
+    vol = vrt.synthetic.treehouse(64, seed=4)
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    res = (200, 120)
+    st = vrt.VoxelRenderSettings.primary_only(res) if mode == "primary_only" else vrt.VoxelRenderSettings(targetResolution=res)
+    st.fsrSetttings.enable = False
+    st.traceSettings.splitKernels = mode == "split"
+    pushes = [camera_push(vrt, (64, 64, 64), res, frame=f, pos=(30.0 + 1.5 * f, 31.0 + 0.5 * f, -50.0 + 3.0 * f), yaw=90.0 - 2.0 * f,
+                          jitter=(0.1 * f - 0.5, 0.25)) for f in range(11)]
+    stage = vrt.GeometryStage(engine, st, gs, debug_planes=True)
+    names = GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "steps_primary", "steps_total", "rays_total"]
+    for shard in (None, vrt.make_shard(1, 3, 16)):
+        batch = [g.numpy() for g in stage.record_batch(pushes, shard)]
+        engine.synchronize()
+        for f, push in enumerate(pushes):
+            single = stage.record(push, shard)
+            engine.synchronize()
+            sn = single.numpy()
+            own = np.ones(res[1], bool) if shard is None else ((np.arange(res[1]) // 16) % 3) == 1     # a rank writes its strips only
+            bad = compare_planes({n: batch[f][n][own] for n in names}, {n: sn[n][own] for n in names}, names)
+            assert not bad, (f, shard is not None, bad)
+        if shard is None:
+            for f in (0, 7, 10):
+                exp = oracle.render(osn, pushes[f], oracle.params_from(st.to_c()), nthreads=8)
+                assert not compare_planes(batch[f], exp, names), f
+    assert any((b["hit_id"] != batch[0]["hit_id"]).any() for b in batch[1:])           # the poses really differ

@@ -88,3 +88,60 @@ def test_sharded_denoise_with_halo(vrt, engine, nranks, strip_rows, iters):
         vrt._capi.check(lib.vrt_unpack_rows(ctx, packed.data_ptr(), final.data_ptr(), W, H, 4, C.byref(sh)))
     engine.synchronize()
     assert (final == full).all(), int((final != full).sum())
+
+
+def test_batched_strip_copies_equal_single_ones(vrt, engine):
+    """vrt_pack_rows_batch / vrt_unpack_rows_batch (frames x source ranks in one launch) against the per-image calls."""
+    import ctypes as C
+    import torch
+    W, H, F, N = 200, 150, 5, 3
+    dev = engine.torch_device
+    L, ctx = vrt.lib(), engine.ctx
+    rng = np.random.default_rng(3)
+    fulls = [torch.from_numpy(rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)).to(dev) for _ in range(F)]
+    prow = vrt.distributed.packed_rows(H, N, 16)
+    P = C.c_void_p
+    packed_by_rank = []
+    for rank in range(N):
+        sh = vrt._capi.Shard(rank, N, 16)
+        batch = torch.full((F, prow, W, 4), 77, dtype=torch.uint8, device=dev)
+        vrt._capi.check(L.vrt_pack_rows_batch(ctx, F, (P * F)(*[t.data_ptr() for t in fulls]), (P * F)(*[batch[f].data_ptr() for f in range(F)]),
+                                              W, H, 4, C.byref(sh)))
+        for f in range(F):
+            one = torch.full((prow, W, 4), 77, dtype=torch.uint8, device=dev)
+            vrt._capi.check(L.vrt_pack_rows(ctx, fulls[f].data_ptr(), one.data_ptr(), W, H, 4, C.byref(sh)))
+            engine.synchronize()
+            assert (one == batch[f]).all(), (rank, f)
+        packed_by_rank.append(batch)
+    outs = torch.zeros((F, H, W, 4), dtype=torch.uint8, device=dev)
+    n = F * N
+    src = (P * n)(*[packed_by_rank[s][f].data_ptr() for s in range(N) for f in range(F)])
+    dst = (P * n)(*[outs[f].data_ptr() for s in range(N) for f in range(F)])
+    shards = (vrt._capi.Shard * n)(*[vrt._capi.Shard(s, N, 16) for s in range(N) for f in range(F)])
+    vrt._capi.check(L.vrt_unpack_rows_batch(ctx, n, src, dst, W, H, 4, shards))
+    engine.synchronize()
+    for f in range(F):
+        assert (outs[f] == fulls[f]).all(), f                  # pack on every rank + unpack at the root = identity
+    assert L.vrt_unpack_rows_batch(ctx, n, src, dst, W, H, 4, None) != 0
+
+
+def test_sharded_batch_assembles_to_the_unsharded_frames(vrt, engine):
+    """ShardedBatch (bench.py's N > 1 path) with the collective replaced by device copies: three simulated ranks render,
+    pack and hand over their strips of a 5-frame batch; the root's assembled frames must equal the unsharded renders."""
+    import torch
+    vol = vrt.synthetic.treehouse(48, seed=6)
+    sc = vrt.VoxelScene.from_dense(engine, vol, vrt.synthetic.default_palette(), sky=vrt.synthetic.sky_gradient(64, 32))
+    res, F, N = (208, 136), 5, 3
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    pushes = [vrt.make_push(vrt.CameraController(position=(24.0 + f, 25.0, -40.0 + 2.0 * f)), (48, 48, 48), res) for f in range(F)]
+    ref = [g.color.clone() for g in vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, 0, 1).step(pushes)]
+    ranks = [vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, r, N) for r in range(N)]
+    bufs = ranks[0].recv_buffers()
+    for r, sb in enumerate(ranks):
+        sb.render(pushes)
+        bufs[r].copy_(sb.pack())                                # stands in for the gather
+    finals = ranks[0].assemble()
+    engine.synchronize()
+    for f in range(F):
+        assert (finals[f] == ref[f]).all(), f
+    assert any((ref[f] != ref[0]).any().item() for f in range(1, F))

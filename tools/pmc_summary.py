@@ -8,6 +8,7 @@ import csv, glob, json, os, sys, collections
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 kernel = sys.argv[2] if len(sys.argv) > 2 else "k_primary<4"
+frames_per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 out = {}
 for d in sorted(glob.glob("gpurun_out/pmc_*/")):
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
@@ -17,7 +18,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_*/")):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
-res = {"kernel": kernel, "counters": out}
+res = {"kernel": kernel, "frames_per_launch": frames_per_launch, "counters": out}
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     f, w = out["FETCH_SIZE"]["mean_per_launch"] * 1024, out["WRITE_SIZE"]["mean_per_launch"] * 1024
     res["hbm_bytes_per_launch"] = {"fetch_raw": f, "fetch_gfx950_x2": 2 * f, "write": w,

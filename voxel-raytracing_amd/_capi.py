@@ -90,6 +90,7 @@ SYMBOLS = {
     "vrt_scene_free": (None, [_P, _P]),
     "vrt_settings_default": (None, [C.POINTER(Settings)]),
     "vrt_render_geometry": (C.c_int, [_P, _P, C.POINTER(Push), C.POINTER(Settings), C.POINTER(Frame), C.POINTER(Shard)]),
+    "vrt_render_geometry_batch": (C.c_int, [_P, _P, C.c_int32, C.POINTER(Push), C.POINTER(Settings), C.POINTER(Frame), C.POINTER(Shard)]),
     "vrt_denoiser_settings_default": (None, [C.POINTER(DenoiserSettings)]),
     "vrt_denoise": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(DenoiserSettings), _P, _P, _P, _P, _P,
                               C.POINTER(Shard), C.POINTER(_P)]),
@@ -97,6 +98,8 @@ SYMBOLS = {
     "vrt_shard_rows": (C.c_int, [C.c_int32, C.POINTER(Shard)]),
     "vrt_pack_rows": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
     "vrt_unpack_rows": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
+    "vrt_pack_rows_batch": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
+    "vrt_unpack_rows_batch": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
     "vrt_pack_halo": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
     "vrt_unpack_halo": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
     "vrt_halo_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32]),

@@ -483,30 +483,42 @@ int vrt_shard_rows(int32_t H, const vrt_shard* sh)
 
 // ---- geometry stage --------------------------------------------------------------------------------
 
-int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, const vrt_settings* st,
-                        const vrt_frame* frame, const vrt_shard* shard)
+// One launch of K1 over n <= VRT_MAX_BATCH frames (K2 follows per frame in split mode, which renders one frame at a time).
+static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* pushes, const vrt_settings* st,
+                         const vrt_frame* frames, const vrt_shard* shard)
 {
-    if (!c || !s || !push || !st || !frame) return fail(VRT_ERR_INVALID, "vrt_render_geometry: NULL argument");
+    const vrt_push* push = &pushes[0];
     int W = push->screen_size[0], H = push->screen_size[1];
     if (W <= 0 || H <= 0 || W > 32768 || H > 32768) return fail(VRT_ERR_INVALID, "vrt_render_geometry: bad screen_size");
-    if (push->volume_bounds[0] != (uint32_t)s->d.vol.W || push->volume_bounds[1] != (uint32_t)s->d.vol.H || push->volume_bounds[2] != (uint32_t)s->d.vol.D)
-        return fail(VRT_ERR_INVALID, "vrt_render_geometry: push.volume_bounds must equal the scene dimensions (voxel_renderer.cpp:74)");
+    for (int f = 0; f < n; f++) {
+        const vrt_push& q = pushes[f];
+        if (q.screen_size[0] != W || q.screen_size[1] != H)
+            return fail(VRT_ERR_INVALID, "vrt_render_geometry_batch: all frames of a batch must have the same screen_size");
+        if (q.volume_bounds[0] != (uint32_t)s->d.vol.W || q.volume_bounds[1] != (uint32_t)s->d.vol.H || q.volume_bounds[2] != (uint32_t)s->d.vol.D)
+            return fail(VRT_ERR_INVALID, "vrt_render_geometry: push.volume_bounds must equal the scene dimensions (voxel_renderer.cpp:74)");
+    }
     if (st->max_bounces > VRT_MAX_BOUNCES) return fail(VRT_ERR_INVALID, "vrt_render_geometry: max_bounces > VRT_MAX_BOUNCES");
     if (st->traversal > VRT_TRAVERSAL_DFJ) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
     if (st->traversal == VRT_TRAVERSAL_DENSE && (uint64_t)s->d.vol.W * (uint64_t)s->d.vol.H * (uint64_t)s->d.vol.D > 0xFFFFFFFFull)
         return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: VRT_TRAVERSAL_DENSE indexes voxels in 32 bits (volumes below 4 GiB)");
     HIPCHK(hipSetDevice(c->device));
     {
-        const void* ptrs[13] = {frame->color8, frame->depth, frame->motion, frame->mask8, frame->position, frame->normal8, frame->color_f,
-                                frame->hit_id, frame->hit_voxel, frame->hit_mask, frame->steps_primary, frame->steps_total, frame->rays_total};
-        int prc = check_device_ptrs(c, 0, ptrs, 13, "vrt_render_geometry");
+        const void* ptrs[13 * VRT_MAX_BATCH];
+        for (int f = 0; f < n; f++) {
+            const vrt_frame* frame = &frames[f];
+            const void* one[13] = {frame->color8, frame->depth, frame->motion, frame->mask8, frame->position, frame->normal8, frame->color_f,
+                                   frame->hit_id, frame->hit_voxel, frame->hit_mask, frame->steps_primary, frame->steps_total, frame->rays_total};
+            memcpy(&ptrs[13 * f], one, sizeof one);
+        }
+        int prc = check_device_ptrs(c, 0, ptrs, 13 * n, "vrt_render_geometry");
         if (prc != VRT_OK) return prc;
     }
 
     GeomParams p;
     memset(&p, 0, sizeof p);
-    p.sc = s->d; p.pc = *push; p.st = *st; p.fr = *frame;
-    p.rg = raygen_consts(*push);
+    p.sc = s->d; p.st = *st;
+    p.n_frames = n; p.W = W; p.H = H;
+    for (int f = 0; f < n; f++) { p.slot[f].pc = pushes[f]; p.slot[f].fr = frames[f]; p.slot[f].rg = raygen_consts(pushes[f]); }
     int rc = make_shard(shard, H, p.sh, nullptr);
     if (rc != VRT_OK) return rc;
     // LDS-staged traversals amortise the staging over a 16x16 tile (4 waves); the others run one 8x8 wave per workgroup,
@@ -520,6 +532,8 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     p.tiles_y_local = p.sh.n_local_strips * (p.sh.strip_rows / p.tile_h);
     p.total_tiles = p.tiles_x * p.tiles_y_local;
     p.chunk = p.tiles_x * ceil_div(p.tiles_y_local, 8);      // workgroups per XCD slot (tile rows are dealt round-robin)
+    p.wgs_per_frame = (uint32_t)p.chunk * 8u;
+    p.wgs_per_frame_rcp = p.wgs_per_frame ? (uint32_t)(0x100000000ull / (uint64_t)p.wgs_per_frame) : 0u;
     p.tps = (uint32_t)(p.sh.strip_rows / p.tile_h);
     p.tiles_x_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tiles_x);
     p.tps_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tps);
@@ -549,6 +563,28 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
     if (c->timing) HIPCHK(hipEventRecord(c->ev_prim1, c->stream));
     if (!p.fused_shade) HIPCHK(launch_shade(p, c->stream));
     if (c->timing) { HIPCHK(hipEventRecord(c->ev_geo1, c->stream)); c->have_geo = true; }
+    return VRT_OK;
+}
+
+int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, const vrt_settings* st,
+                        const vrt_frame* frame, const vrt_shard* shard)
+{
+    if (!c || !s || !push || !st || !frame) return fail(VRT_ERR_INVALID, "vrt_render_geometry: NULL argument");
+    return render_frames(c, s, 1, push, st, frame, shard);
+}
+
+int vrt_render_geometry_batch(vrt_ctx* c, const vrt_scene* s, int32_t n, const vrt_push* pushes, const vrt_settings* st,
+                              const vrt_frame* frames, const vrt_shard* shard)
+{
+    if (!c || !s || !pushes || !st || !frames) return fail(VRT_ERR_INVALID, "vrt_render_geometry_batch: NULL argument");
+    if (n < 0) return fail(VRT_ERR_INVALID, "vrt_render_geometry_batch: n < 0");
+    // the split form keeps one frame's hit records: one frame per launch there
+    const int per_launch = (st->flags & VRT_FLAG_SPLIT_KERNELS) && !(st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : VRT_MAX_BATCH;
+    for (int f0 = 0; f0 < n; f0 += per_launch) {
+        int m = n - f0 < per_launch ? n - f0 : per_launch;
+        int rc = render_frames(c, s, m, pushes + f0, st, frames + f0, shard);
+        if (rc != VRT_OK) return rc;
+    }
     return VRT_OK;
 }
 
@@ -653,6 +689,44 @@ int vrt_unpack_halo(vrt_ctx* c, const void* packed, void* full, int32_t W, int32
 {
     if (halo <= 0 || (dir != -1 && dir != 1)) return fail(VRT_ERR_INVALID, "vrt_unpack_halo: halo > 0 and dir = +-1 required");
     return rows_call(c, packed, full, W, H, bpp, sh, halo, dir, 1);
+}
+
+// n images per launch (chunks of VRT_ROWS_BATCH).  shards: one map for all images (per_image == 0) or one per image.
+static int rows_batch_call(vrt_ctx* c, int n, const void* const* src, void* const* dst, int W, int H, int bpp,
+                           const vrt_shard* shards, int per_image, int unpack)
+{
+    if (!c || !src || !dst) return fail(VRT_ERR_INVALID, "strip copy (batch): NULL argument");
+    if (n < 0 || W <= 0 || H <= 0 || bpp <= 0) return fail(VRT_ERR_INVALID, "strip copy (batch): bad size");
+    HIPCHK(hipSetDevice(c->device));
+    for (int i0 = 0; i0 < n; i0 += VRT_ROWS_BATCH) {
+        const int m = n - i0 < VRT_ROWS_BATCH ? n - i0 : VRT_ROWS_BATCH;
+        RowsBatchParams p;
+        memset(&p, 0, sizeof p);
+        p.W = W; p.H = H; p.bpp = bpp; p.unpack = unpack;
+        int rows = 0;
+        for (int k = 0; k < m; k++) {
+            if (!src[i0 + k] || !dst[i0 + k]) return fail(VRT_ERR_INVALID, "strip copy (batch): NULL image pointer");
+            int mx = 1;
+            int rc = make_shard(per_image ? &shards[i0 + k] : shards, H, p.sh[k], &mx);
+            if (rc != VRT_OK) return rc;
+            p.src[k] = (const uint8_t*)src[i0 + k]; p.dst[k] = (uint8_t*)dst[i0 + k];
+            int r = p.sh[k].nranks == 1 ? H : mx * p.sh[k].strip_rows;
+            rows = r > rows ? r : rows;
+        }
+        HIPCHK(launch_rows_batch(p, rows, m, c->stream));
+    }
+    return VRT_OK;
+}
+
+int vrt_pack_rows_batch(vrt_ctx* c, int32_t n, const void* const* full, void* const* packed, int32_t W, int32_t H, int32_t bpp,
+                        const vrt_shard* shard)
+{ return rows_batch_call(c, n, full, packed, W, H, bpp, shard, 0, 0); }
+
+int vrt_unpack_rows_batch(vrt_ctx* c, int32_t n, const void* const* packed, void* const* full, int32_t W, int32_t H, int32_t bpp,
+                          const vrt_shard* shards)
+{
+    if (!shards) return fail(VRT_ERR_INVALID, "vrt_unpack_rows_batch: one vrt_shard per image is required");
+    return rows_batch_call(c, n, packed, full, W, H, bpp, shards, 1, 1);
 }
 
 size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bpp, const vrt_shard* sh, int32_t halo)

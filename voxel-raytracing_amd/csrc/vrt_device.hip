@@ -189,7 +189,7 @@ __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 s
 // shading helpers
 // ---------------------------------------------------------------------------------------------
 
-struct PixCtx { int px, py; uint32_t fetches, rays; };
+struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; };   // pc: the push block of the pixel's frame
 
 // skyColor, voxel_volume.frag:98-105
 __device__ __forceinline__ f3 sky_color(const DevScene& s, f3 d)
@@ -220,14 +220,14 @@ __device__ __forceinline__ f3 random_dir(const DevScene& s, const vrt_push& pc, 
 }
 
 // main() ray generation, voxel_volume.frag:312-322 (+ screen_quad.vert:18-31)
-__device__ __forceinline__ f3 primary_dir(const GeomParams& P, int px, int py)
+__device__ __forceinline__ f3 primary_dir(const FrameSlot& S, int px, int py)
 {
-    const RayGenConsts& g = P.rg;
+    const RayGenConsts& g = S.rg;
     float sx = (((float)px + 0.5f) / g.W) * 2.0f - 1.0f;
     float sy = (((float)py + 0.5f) / g.H) * 2.0f - 1.0f;
-    float vx = ((g.cd.x + sx * P.pc.cam_right[0]) + sy * g.planeV.x) + g.jx;
-    float vy = ((g.cd.y + sx * P.pc.cam_right[1]) + sy * g.planeV.y) + g.jy;
-    float vz = ((g.cd.z + sx * P.pc.cam_right[2]) + sy * g.planeV.z) + 0.0f;
+    float vx = ((g.cd.x + sx * S.pc.cam_right[0]) + sy * g.planeV.x) + g.jx;
+    float vy = ((g.cd.y + sx * S.pc.cam_right[1]) + sy * g.planeV.y) + g.jy;
+    float vz = ((g.cd.z + sx * S.pc.cam_right[2]) + sy * g.planeV.z) + 0.0f;
     return normalize3(mk3(vx, vy, vz));
 }
 
@@ -247,7 +247,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
     } else {
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
-            f3 rd = random_dir(s, P.pc, c, i + depth * st.ao_samples);
+            f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
             f3 dir = mk3(hit.normal.x + rd.x, hit.normal.y + rd.y, hit.normal.z + rd.z);
             f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
             RayInt r;
@@ -335,9 +335,12 @@ __device__ __forceinline__ uint32_t udiv_uniform(uint32_t n, uint32_t d, uint32_
     return q;
 }
 
-__device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y0)
+__device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y0, uint32_t& frame)
 {
+    // frames of a batch follow one another in the grid: the next frame's first tiles start while this one drains
     uint32_t b = blockIdx.x;
+    frame = 0;
+    if (P.n_frames > 1) frame = udiv_uniform(blockIdx.x, P.wgs_per_frame, P.wgs_per_frame_rcp, b);
     // XCD slot (b & 7) owns tile rows ty with ty % 8 == slot: every XCD gets an even sample of sky and
     // geometry (a contiguous band per XCD leaves the XCDs that drew the sky idle), while the tiles of one
     // row -- which walk neighbouring volume cells -- still share that XCD's L2.
@@ -351,7 +354,7 @@ __device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y
     int strip_local = (int)udiv_uniform((uint32_t)ty, P.tps, P.tps_rcp, within);
     x0 = tx * P.tile_w;
     y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + (int)within * P.tile_h;
-    return y0 < P.pc.screen_size[1];
+    return y0 < P.H;
 }
 
 // Stage the 16^3 and 64^3 occupancy summaries into LDS (16 B per lane per iteration, coalesced).
@@ -388,8 +391,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     const uint64_t t_begin = (P.st.flags & 2u) ? wall_clock64() : 0ull;      // diagnostic timeline (100 MHz)
     int x0, y0;
-    bool live = tile_origin(P, x0, y0);          // uniform per workgroup
+    uint32_t frame;
+    bool live = tile_origin(P, x0, y0, frame);          // uniform per workgroup
     if (!live) return;
+    const FrameSlot& S = P.slot[frame];
     constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
     const OccT<kLds> occ = stage_occ<kLds>(P, lds_occ);
 
@@ -399,18 +404,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int px = x0 + (wave & 1) * 8 + (lane & 7);
     int py = y0 + (wave >> 1) * 8 + (lane >> 3);
-    int W = P.pc.screen_size[0], H = P.pc.screen_size[1];
+    int W = P.W, H = P.H;
     if (px >= W || py >= H) return;
     size_t i = (size_t)py * (size_t)W + (size_t)px;
 
     const DevScene& s = P.sc;
-    f3 start = mk3(P.pc.cam_pos[0], P.pc.cam_pos[1], P.pc.cam_pos[2]);
-    f3 dir = primary_dir(P, px, py);
+    f3 start = mk3(S.pc.cam_pos[0], S.pc.cam_pos[1], S.pc.cam_pos[2]);
+    f3 dir = primary_dir(S, px, py);
     RayHit h; RayInt r;
     trace_ray<TRAV>(s, occ, start, dir, P.st.max_steps, h, r);
     bool hit = h.material != 0;
 
-    const vrt_frame& f = P.fr;
+    const vrt_frame& f = S.fr;
     float depth = 0.0f;
     if (hit) depth = len3(mk3(h.pos.x - start.x, h.pos.y - start.y, h.pos.z - start.z));
     if (f.depth) f.depth[i] = depth;
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (MODE != 0) {
         f3 col;
         if (hit) {
-            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
+            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &S.pc;
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 col = color_main_ray<TRAV>(P, occ, c, h);
@@ -490,20 +495,20 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid >= count) return;
     size_t i = P.hit_list[gid];
-    int W = P.pc.screen_size[0];
+    int W = P.W;
     int px = (int)(i % (size_t)W), py = (int)(i / (size_t)W);
 
     uint4 rec = P.records[i];
     RayHit h;
     h.material = rec.w & 0xFFu;
-    h.dir = primary_dir(P, px, py);
+    h.dir = primary_dir(P.slot[0], px, py);
     h.pos = mk3(__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z));
     uint32_t mask = (rec.w >> 8) & 7u;
     int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;
-    PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0;
+    PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &P.slot[0].pc;
     h.normal = hit_normal(mask, sx, sy, sz);
     f3 col = color_main_ray<TRAV>(P, occ, c, h);
-    const vrt_frame& f = P.fr;
+    const vrt_frame& f = P.slot[0].fr;
     if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
     if (f.color8) {
         uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
 template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
-    dim3 grid((unsigned)(p.chunk * 8)), block(p.tile_h == 8 ? 64 : 256);
+    dim3 grid((unsigned)(p.chunk * 8) * (unsigned)p.n_frames), block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1>), grid, block, lds, s, p);
     else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2>), grid, block, lds, s, p);
@@ -881,6 +886,39 @@ __global__ __launch_bounds__(256) void k_rows(const RowsParams P)
     } else {
         for (size_t i = threadIdx.x; i < row_bytes; i += blockDim.x) dst[i] = src[i];
     }
+}
+
+// The same for up to VRT_ROWS_BATCH images in one launch (the frames of a batch; at the root of a gather: frames x source
+// ranks, each with its own strip map): one small launch per image would cost more than the copies.
+__global__ __launch_bounds__(256) void k_rows_batch(const RowsBatchParams P)
+{
+    const int r = blockIdx.x, img = blockIdx.y;
+    const ShardMap sh = P.sh[img];
+    const int y = strip_row(sh, 0, r, P.H);
+    const size_t row_bytes = (size_t)P.W * (size_t)P.bpp;
+    const uint8_t* src; uint8_t* dst;
+    if (y < 0) {
+        if (P.unpack) return;
+        dst = P.dst[img] + (size_t)r * row_bytes;                  // rows that do not exist: zero-fill the packed slot
+        for (size_t i = threadIdx.x; i < row_bytes; i += blockDim.x) dst[i] = 0;
+        return;
+    }
+    if (P.unpack) { src = P.src[img] + (size_t)r * row_bytes; dst = P.dst[img] + (size_t)y * row_bytes; }
+    else          { src = P.src[img] + (size_t)y * row_bytes; dst = P.dst[img] + (size_t)r * row_bytes; }
+    if ((row_bytes & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (size_t i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) d4[i] = s4[i];
+    } else {
+        for (size_t i = threadIdx.x; i < row_bytes; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+hipError_t launch_rows_batch(const RowsBatchParams& p, int rows_total, int images, hipStream_t s)
+{
+    if (rows_total <= 0 || images <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rows_batch, dim3((unsigned)rows_total, (unsigned)images), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_rows(const RowsParams& p, int rows_total, hipStream_t s)

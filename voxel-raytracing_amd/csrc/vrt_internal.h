@@ -50,12 +50,25 @@ inline RayGenConsts raygen_consts(const vrt_push& pc)
     return g;
 }
 
-struct GeomParams {
+// One frame of a launch: camera (push block + its hoisted part) and output planes.
+struct FrameSlot {
     RayGenConsts rg;
+    vrt_push     pc;
+    vrt_frame    fr;
+};
+
+#define VRT_MAX_BATCH 8      // frames per K1 launch (vrt_render_geometry_batch); 8 x 248 B of kernel arguments
+
+struct GeomParams {
+    // A launch covers n_frames frames of one scene, one resolution and one set of settings (consecutive camera poses of an
+    // animation, or the frames of a multi-GPU batch): workgroup b works on frame b / wgs_per_frame.  Frame f+1's tiles are
+    // dispatched while frame f drains, so the ~30 us tail of a frame is paid once per launch instead of once per frame.
+    FrameSlot  slot[VRT_MAX_BATCH];
+    int32_t    n_frames;
+    uint32_t   wgs_per_frame, wgs_per_frame_rcp;   // chunk * 8 and floor(2^32 / that)
+    int32_t    W, H;                               // screen size (common to the frames)
     DevScene   sc;
-    vrt_push   pc;
     vrt_settings st;
-    vrt_frame  fr;
     ShardMap   sh;
     int32_t    tile_w, tile_h; // workgroup tile in pixels: 16x16 (4 waves of 8x8) or 8x8 (one wave)
     int32_t    tiles_x, tiles_y_local, total_tiles, chunk;  // chunk = tiles per XCD slot
@@ -88,6 +101,14 @@ struct RowsParams {
     int32_t halo, dir, unpack;
 };
 
+#define VRT_ROWS_BATCH 64     // images per k_rows_batch launch (40 B of kernel arguments each)
+struct RowsBatchParams {     // strip pack / unpack of many images in one launch: image blockIdx.y, packed row blockIdx.x
+    const uint8_t* src[VRT_ROWS_BATCH];
+    uint8_t*       dst[VRT_ROWS_BATCH];
+    ShardMap       sh[VRT_ROWS_BATCH];
+    int32_t W, H, bpp, unpack;
+};
+
 struct BlitParams {
     const uint8_t* src; uint8_t* dst;
     int32_t sw, sh, tw, th;
@@ -101,6 +122,7 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s);
 hipError_t launch_shade(const GeomParams& p, hipStream_t s);
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s);
 hipError_t launch_rows(const RowsParams& p, int rows_total, hipStream_t s);
+hipError_t launch_rows_batch(const RowsBatchParams& p, int rows_total, int images, hipStream_t s);
 hipError_t launch_blit(const BlitParams& p, hipStream_t s);
 hipError_t launch_accumulate(const void* color_rgba8, void* accum_u32x4, size_t n, int reset, hipStream_t s);
 hipError_t launch_resolve(const void* accum_u32x4, void* out_rgba8, size_t n, uint32_t frames, hipStream_t s);

@@ -202,3 +202,76 @@ class ShardedFrame:
 
     def step(self):
         return self.gather(self.pack(self.render_local()))
+
+
+class ShardedBatch:
+    """Per-rank driver for a batch of F frames (consecutive camera poses): ONE K1 launch per 8 frames over this rank's strips
+    of all of them (vrt_render_geometry_batch), one strip-pack launch, ONE gather of the whole batch to rank 0, one unpack
+    launch per 64 (frame, source) pairs there.  Geometry only (the denoiser needs the halo exchange of ShardedFrame)."""
+
+    def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None):
+        import torch
+        self.stage, self.F = stage, int(n_frames)
+        self.rank, self.nranks, self.group = int(rank), int(nranks), group
+        W, H = stage._settings.renderResolution()
+        self.W, self.H = W, H
+        self.strip_rows = strip_rows or default_strip_rows(H, nranks)
+        self.shard = _capi.Shard(self.rank, self.nranks, self.strip_rows) if nranks > 1 else None
+        self.launch = stage.prepare_batch(self.F, self.shard)
+        self.gbs = self.launch._keepalive[4]
+        dev = stage.engine.torch_device
+        self.prow = packed_rows(H, nranks, self.strip_rows)
+        if nranks > 1:
+            self.packed = torch.zeros((self.F, self.prow, W, 4), dtype=torch.uint8, device=dev)
+            P = C.c_void_p
+            self._full_ptrs = (P * self.F)(*[g.color.data_ptr() for g in self.gbs])
+            self._packed_ptrs = (P * self.F)(*[self.packed[f].data_ptr() for f in range(self.F)])
+            self._root = None
+            if rank == 0:
+                self.finals = torch.zeros((self.F, H, W, 4), dtype=torch.uint8, device=dev)
+
+    def render(self, pushes):
+        """This rank's strips of every frame; returns the GeometryBuffers (own rows valid)."""
+        return self.launch(pushes)
+
+    def pack(self):
+        _capi.check(_capi.lib().vrt_pack_rows_batch(self.stage.engine.ctx, self.F, self._full_ptrs, self._packed_ptrs, self.W, self.H, 4,
+                                                    C.byref(self.shard)))
+        return self.packed
+
+    def recv_buffers(self):
+        """Rank 0: the per-source receive buffers of the gather ([F, packed rows, W, 4] each) and, built once, the pointer
+        tables of the (frame, source) unpack."""
+        import torch
+        if self._root is None:
+            bufs = [torch.empty_like(self.packed) for _ in range(self.nranks)]
+            P = C.c_void_p
+            n = self.F * self.nranks
+            src = (P * n)(*[bufs[s][f].data_ptr() for s in range(self.nranks) for f in range(self.F)])
+            dst = (P * n)(*[self.finals[f].data_ptr() for s in range(self.nranks) for f in range(self.F)])
+            shards = (_capi.Shard * n)(*[_capi.Shard(s, self.nranks, self.strip_rows) for s in range(self.nranks) for f in range(self.F)])
+            self._root = (bufs, n, src, dst, shards)
+        return self._root[0]
+
+    def assemble(self):
+        """Rank 0, after the gather filled recv_buffers(): every frame of the batch into self.finals (one launch per 64
+        (frame, source) pairs)."""
+        _, n, src, dst, shards = self._root
+        _capi.check(_capi.lib().vrt_unpack_rows_batch(self.stage.engine.ctx, n, src, dst, self.W, self.H, 4, shards))
+        return self.finals
+
+    def gather(self):
+        """One RCCL gather of all frames' packed strips; on rank 0 the frames are assembled into self.finals."""
+        import torch.distributed as dist
+        if self.rank != 0:
+            dist.gather(self.packed, gather_list=None, dst=0, group=self.group)
+            return None
+        dist.gather(self.packed, gather_list=self.recv_buffers(), dst=0, group=self.group)
+        return self.assemble()
+
+    def step(self, pushes):
+        gbs = self.render(pushes)
+        if self.nranks <= 1:
+            return gbs
+        self.pack()
+        return self.gather()

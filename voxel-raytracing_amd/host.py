@@ -220,7 +220,10 @@ class Engine:
         l = lib()
         self.device = int(device)
         torch = _torch()
-        torch.cuda.init()                        # torch's HIP runtime first (see _capi.lib)
+        try:
+            torch.cuda.init()                    # torch's HIP runtime first (see _capi.lib)
+        except Exception:
+            pass                                 # no GPU: vrt_ctx_create below reports it (VRT_ERR_NO_DEVICE, no CPU fallback)
         self._ctx = C.c_void_p()
         check(l.vrt_ctx_create(self.device, C.byref(self._ctx)))
         self.torch_device = torch.device("cuda", self.device)      # where the stages allocate their images
@@ -540,6 +543,32 @@ class GeometryStage:
             return gb
         launch._keepalive = (st, fr, shard, gb)
         return launch
+
+    def prepare_batch(self, n: int, shard: Optional[_capi.Shard] = None):
+        """n frames per launch (vrt_render_geometry_batch): consecutive poses of an animation or the frames of a multi-GPU
+        batch.  Returns launch(pushes) -> [GeometryBuffer] * n; every frame has its own planes, allocated here once."""
+        W, H = self._settings.renderResolution()
+        planes = GBUFFER_PLANES + (DEBUG_PLANES if self._debug else ())
+        gbs = [GeometryBuffer(self.engine, W, H, planes) for _ in range(int(n))]
+        st = self._settings.to_c()
+        frs = (_capi.Frame * int(n))(*[g.to_c() for g in gbs])
+        arr = (_capi.Push * int(n))()
+        fn, ctx, scene = lib().vrt_render_geometry_batch, self.engine.ctx, self._scene.handle
+        pst = C.byref(st)
+        psh = C.byref(shard) if shard is not None else None
+
+        def launch(pushes) -> list:
+            for k, p in enumerate(pushes):
+                arr[k] = p
+            rc = fn(ctx, scene, len(pushes), arr, pst, frs, psh)
+            if rc != 0:
+                check(rc)
+            return gbs[:len(pushes)]
+        launch._keepalive = (st, frs, arr, shard, gbs)
+        return launch
+
+    def record_batch(self, pushes, shard: Optional[_capi.Shard] = None) -> list:
+        return self.prepare_batch(len(pushes), shard)(pushes)
 
 
 class DenoiserStage:
