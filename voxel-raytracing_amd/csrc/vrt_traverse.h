@@ -441,7 +441,12 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     uint32_t material = 0, fetches = 0;
     // the mask of the latest iteration, one bool per axis: the compiler keeps each as a 64-bit lane mask in scalar
     // registers (the compare results themselves), so recording it costs no vector instructions
+    // (device: three wave-wide lane masks, updated by the EXEC masks of the run's last iteration -- scalar moves only)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t m0 = __ballot((s.mask & 1u) != 0u), m1 = __ballot((s.mask & 2u) != 0u), m2 = __ballot((s.mask & 4u) != 0u);
+#else
     bool k0 = (s.mask & 1u) != 0u, k1 = (s.mask & 2u) != 0u, k2 = (s.mask & 4u) != 0u;
+#endif
     // a ray that starts outside the volume and misses it begins the loop at its own origin (frag:118-126) and leaves
     // in iteration 0; every later position is inside the volume or in the one-voxel border of the fields
     bool done = oob(v, s.mx, s.my, s.mz);
@@ -493,6 +498,33 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
             // kw - 1 iterations whose mask nobody will read, then one that records it
             for (uint32_t j = 1; j < kw; j++) dda_advance(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+            {
+                // the same 7-op iteration; the EXEC mask each v_cmpx leaves behind IS the axis' mask bit of the lanes in the
+                // run, copied out by a scalar move and merged into the wave-wide masks with scalar logic
+                uint32_t mn;
+                uint64_t live, kx, ky, kz;
+                asm volatile("v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
+                             "s_mov_b64 %[sv], exec\n\t"
+                             "v_cmpx_eq_u32 %[mn], %[x]\n\t"
+                             "s_mov_b64 %[kx], exec\n\t"
+                             "v_add_f32 %[x], %[x], %[dx]\n\t"
+                             "s_mov_b64 exec, %[sv]\n\t"
+                             "v_cmpx_eq_u32 %[mn], %[y]\n\t"
+                             "s_mov_b64 %[ky], exec\n\t"
+                             "v_add_f32 %[y], %[y], %[dy]\n\t"
+                             "s_mov_b64 exec, %[sv]\n\t"
+                             "v_cmpx_eq_u32 %[mn], %[z]\n\t"
+                             "s_mov_b64 %[kz], exec\n\t"
+                             "v_add_f32 %[z], %[z], %[dz]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [mn] "=&v"(mn), [sv] "=&s"(live),
+                               [kx] "=&s"(kx), [ky] "=&s"(ky), [kz] "=&s"(kz)
+                             : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz)
+                             : "vcc");
+                m0 = (m0 & ~live) | kx; m1 = (m1 & ~live) | ky; m2 = (m2 & ~live) | kz;
+            }
+#else
             {
                 uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
                 uint32_t mn = umin3(bx, by, bz);
@@ -501,6 +533,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
                 s.sdy = k1 ? s.sdy + s.dy : s.sdy;
                 s.sdz = k2 ? s.sdz + s.dz : s.sdz;
             }
+#endif
             const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
             s.mx += nx; s.my += ny; s.mz += nz;
             idx += SMALL ? (IDX)(nx + mul24(ny, pw) + mul24(nz, (int)pwh))
@@ -508,7 +541,13 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         }
         i += kw;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t mask = (uint32_t)((m0 >> lane) & 1ull) | ((uint32_t)((m1 >> lane) & 1ull) << 1) | ((uint32_t)((m2 >> lane) & 1ull) << 2);
+    finish(s, material, mask, fetches, r);
+#else
     finish(s, material, (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2), fetches, r);
+#endif
     r.dbg0 = n_outer; r.dbg1 = n_long;
 }
 
