@@ -315,6 +315,56 @@ VRT_HD void dda_advance(DdaState& s)
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same iteration for use in wave-uniform control flow: only the lanes of `live` advance (EXEC is narrowed to
+// live & "this axis holds the minimum" per axis and put back to its value on entry at the end).
+__device__ __forceinline__ void dda_advance_live(DdaState& s, uint64_t live)
+{
+    uint32_t mn;
+    uint64_t entry;
+    asm volatile("v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
+                 "s_mov_b64 %[en], exec\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[x]\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[y]\n\t"
+                 "v_add_f32 %[y], %[y], %[dy]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[z]\n\t"
+                 "v_add_f32 %[z], %[z], %[dz]\n\t"
+                 "s_mov_b64 exec, %[en]"
+                 : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [mn] "=&v"(mn), [en] "=&s"(entry)
+                 : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz), [lv] "s"(live)
+                 : "vcc");
+}
+// ... and handing out the EXEC mask each v_cmpx leaves behind: it IS that axis' mask bit for the live lanes.
+__device__ __forceinline__ void dda_advance_live_masks(DdaState& s, uint64_t live, uint64_t& kx, uint64_t& ky, uint64_t& kz)
+{
+    uint32_t mn;
+    uint64_t entry;
+    asm volatile("v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
+                 "s_mov_b64 %[en], exec\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[x]\n\t"
+                 "s_mov_b64 %[kx], exec\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[y]\n\t"
+                 "s_mov_b64 %[ky], exec\n\t"
+                 "v_add_f32 %[y], %[y], %[dy]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[z]\n\t"
+                 "s_mov_b64 %[kz], exec\n\t"
+                 "v_add_f32 %[z], %[z], %[dz]\n\t"
+                 "s_mov_b64 exec, %[en]"
+                 : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [mn] "=&v"(mn), [en] "=&s"(entry),
+                   [kx] "=&s"(kx), [ky] "=&s"(ky), [kz] "=&s"(kz)
+                 : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz), [lv] "s"(live)
+                 : "vcc");
+}
+#endif
+
 // ---- wavefront votes (device: the 64 lanes of a gfx950 wave; host tests: a single lane) ------------------
 
 VRT_HD bool wave_all(bool p)
@@ -491,40 +541,31 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         kw = kw < left ? kw : left;
         st_jump(stats, kw > 4u ? 2 : 1);
         if (kw >= 12u) n_long += kw;
-        if (!done) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        {
+            // The run is wave-uniform control flow: every lane executes it, but the stepping asm narrows EXEC to the live
+            // lanes itself, so a finished lane's sideDist stands still, its differences below are 0 and its mapPos /
+            // index do not move.  (Inside a divergent `if (!done)` the three lane masks would be per-lane values: six
+            // VGPRs and twelve VALU ops per look-up to merge them.)
+            const uint64_t live = __ballot(!done);
             // Only sideDist is advanced inside the run; mapPos is recovered afterwards: an axis that took n steps has
             // grown by n (+) additions of delta, so n = round((side - side_before) / delta) -- n <= 63 per run and the
             // accumulated rounding error is orders of magnitude below 1/2.
             const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
-            // kw - 1 iterations whose mask nobody will read, then one that records it
-            for (uint32_t j = 1; j < kw; j++) dda_advance(s);
-#if defined(__HIP_DEVICE_COMPILE__)
-            {
-                // the same 7-op iteration; the EXEC mask each v_cmpx leaves behind IS the axis' mask bit of the lanes in the
-                // run, copied out by a scalar move and merged into the wave-wide masks with scalar logic
-                uint32_t mn;
-                uint64_t live, kx, ky, kz;
-                asm volatile("v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
-                             "s_mov_b64 %[sv], exec\n\t"
-                             "v_cmpx_eq_u32 %[mn], %[x]\n\t"
-                             "s_mov_b64 %[kx], exec\n\t"
-                             "v_add_f32 %[x], %[x], %[dx]\n\t"
-                             "s_mov_b64 exec, %[sv]\n\t"
-                             "v_cmpx_eq_u32 %[mn], %[y]\n\t"
-                             "s_mov_b64 %[ky], exec\n\t"
-                             "v_add_f32 %[y], %[y], %[dy]\n\t"
-                             "s_mov_b64 exec, %[sv]\n\t"
-                             "v_cmpx_eq_u32 %[mn], %[z]\n\t"
-                             "s_mov_b64 %[kz], exec\n\t"
-                             "v_add_f32 %[z], %[z], %[dz]\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [mn] "=&v"(mn), [sv] "=&s"(live),
-                               [kx] "=&s"(kx), [ky] "=&s"(ky), [kz] "=&s"(kz)
-                             : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz)
-                             : "vcc");
-                m0 = (m0 & ~live) | kx; m1 = (m1 & ~live) | ky; m2 = (m2 & ~live) | kz;
-            }
+            // kw - 1 iterations whose mask nobody will read, then one whose EXEC masks are the mask bits
+            for (uint32_t j = 1; j < kw; j++) dda_advance_live(s, live);
+            uint64_t kx, ky, kz;
+            dda_advance_live_masks(s, live, kx, ky, kz);
+            m0 = (m0 & ~live) | kx; m1 = (m1 & ~live) | ky; m2 = (m2 & ~live) | kz;
+            const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
+            s.mx += nx; s.my += ny; s.mz += nz;
+            idx += SMALL ? (IDX)(nx + mul24(ny, pw) + mul24(nz, (int)pwh))
+                         : (IDX)((SIDX)nx + (SIDX)ny * (SIDX)pw + (SIDX)nz * (SIDX)pwh);
+        }
 #else
+        if (!done) {
+            const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
+            for (uint32_t j = 1; j < kw; j++) dda_advance(s);
             {
                 uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
                 uint32_t mn = umin3(bx, by, bz);
@@ -533,12 +574,12 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
                 s.sdy = k1 ? s.sdy + s.dy : s.sdy;
                 s.sdz = k2 ? s.sdz + s.dz : s.sdz;
             }
-#endif
             const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
             s.mx += nx; s.my += ny; s.mz += nz;
             idx += SMALL ? (IDX)(nx + mul24(ny, pw) + mul24(nz, (int)pwh))
                          : (IDX)((SIDX)nx + (SIDX)ny * (SIDX)pw + (SIDX)nz * (SIDX)pwh);
         }
+#endif
         i += kw;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
