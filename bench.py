@@ -6,7 +6,7 @@ algorithmic GB/s of the primary-ray DDA kernel against the MI355X HBM peak.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input: a batch of N x F frames (N = number of GPUs,
-F = --frames-per-gpu, default 4; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips
+F = --frames-per-gpu, default 8; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips
 that are dealt round-robin to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch per
 8 frames (vrt_render_geometry_batch: the next frame's tiles are dispatched while the previous frame drains), packs
 them with one launch, and the batch is gathered to rank 0 with ONE RCCL gather per step and assembled there with one
@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
-    ap.add_argument("--frames-per-gpu", type=int, default=4, help="frames of the batch per GPU and step")
+    ap.add_argument("--frames-per-gpu", type=int, default=8, help="frames of the batch per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
