@@ -84,10 +84,15 @@ def main():
     sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world)
     launches_per_step = (F + 7) // 8                          # K1 launches per rank and step
 
+    overlap = os.environ.get("VRT_SYNC_GATHER", "0") != "1"
+
     def step():
-        sb.step(pushes)       # K1 over this rank's strips of the F frames (+ pack, ONE RCCL gather, unpack on rank 0)
+        # K1 over this rank's strips of the F frames, then pack + ONE RCCL gather (+ assembly on rank 0); the gather of a
+        # step runs while the next step is traced (VRT_SYNC_GATHER=1: strictly one after the other)
+        sb.step(pushes, overlap)
 
     def barrier():
+        sb.finish()                                           # the gather still in flight, and its assembly on rank 0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

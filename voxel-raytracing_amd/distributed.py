@@ -269,9 +269,37 @@ class ShardedBatch:
         dist.gather(self.packed, gather_list=self.recv_buffers(), dst=0, group=self.group)
         return self.assemble()
 
-    def step(self, pushes):
+    # -- the gather of step k overlapped with the tracing of step k + 1 -----------------------------------------------
+    def start_gather(self):
+        """Enqueue the gather without making the launch stream wait for it (async_op: the collective runs on RCCL's own
+        stream, ordered after the pack by an event)."""
+        import torch.distributed as dist
+        bufs = self.recv_buffers() if self.rank == 0 else None
+        self._work = dist.gather(self.packed, gather_list=bufs, dst=0, group=self.group, async_op=True)
+
+    def finish(self):
+        """Make the launch stream wait for the gather in flight (if any) and, on rank 0, assemble its frames.  Returns
+        self.finals on rank 0 when a gather was completed, else None."""
+        w = getattr(self, "_work", None)
+        if w is None:
+            return None
+        w.wait()
+        self._work = None
+        return self.assemble() if self.rank == 0 else None
+
+    def step(self, pushes, overlap: bool = True):
+        """One step.  overlap=True: this step's K1 is launched first and runs while the previous step's gather is still in
+        flight; then that gather is completed (rank 0 assembles ITS frames), this step's strips are packed and their
+        gather is started.  The caller ends a sequence with finish().  Returns the frames completed by this call on rank 0
+        (the previous step's with overlap, this step's without; None elsewhere / on the first overlapped step);
+        N = 1: this step's GeometryBuffers."""
         gbs = self.render(pushes)
         if self.nranks <= 1:
             return gbs
+        if not overlap:
+            self.pack()
+            return self.gather()
+        out = self.finish()
         self.pack()
-        return self.gather()
+        self.start_gather()
+        return out
