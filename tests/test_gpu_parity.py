@@ -317,3 +317,37 @@ def test_batch_of_frames_equals_single_calls(vrt, oracle, engine, mode):
                 exp = oracle.render(osn, pushes[f], oracle.params_from(st.to_c()), nthreads=8)
                 assert not compare_planes(batch[f], exp, names), f
     assert any((b["hit_id"] != batch[0]["hit_id"]).any() for b in batch[1:])           # the poses really differ
+
+
+def test_two_contexts_share_a_scene(vrt, oracle, engine):
+    """One context per frame in flight (MAX_FRAMES_IN_FLIGHT = 2, engine.hpp:19): two contexts with their own streams render
+    alternate poses of one scene concurrently; every frame must be the oracle's."""
+    import torch
+    vol = vrt.synthetic.treehouse(48, seed=9)
+    pal = metallic_palette(vrt)
+    gs, osn = _scene_pair(vrt, oracle, engine, vol, pal)
+    engine.synchronize()
+    res = (160, 96)
+    st = vrt.VoxelRenderSettings(targetResolution=res)
+    st.fsrSetttings.enable = False
+    st.occlusionSettings.numSamples = 2
+    slots = [vrt.Engine(0, use_torch_stream=False) for _ in range(2)]
+    torch.cuda.synchronize()
+    stages = [vrt.GeometryStage(e, st, gs) for e in slots]
+    pushes = [camera_push(vrt, (48, 48, 48), res, frame=f, pos=(22.0 + f, 25.0, -40.0 + 1.5 * f)) for f in range(6)]
+    torch.cuda.synchronize()                                   # the planes were zero-filled on torch's stream
+    outs = []
+    for f, push in enumerate(pushes):
+        e = slots[f % 2]
+        if f >= 2:
+            e.synchronize()                                    # the slot's previous frame is about to be overwritten
+            outs.append(stages[f % 2]._buffer.numpy())
+        stages[f % 2].record(push)
+    for k in (0, 1):
+        slots[(len(pushes) + k) % 2].synchronize()
+        outs.append(stages[(len(pushes) + k) % 2]._buffer.numpy())
+    for f, push in enumerate(pushes):
+        exp = oracle.render(osn, push, oracle.params_from(st.to_c()), nthreads=8)
+        assert not compare_planes(outs[f], exp, GB), f
+    for e in slots:
+        e.destroy()

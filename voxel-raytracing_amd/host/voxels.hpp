@@ -190,8 +190,32 @@ public:
         check(vrt_render_geometry(engine->ctx, scene->handle, &push, &st, &f, shard));
         return gb;
     }
+    // n camera poses in one launch per 8 frames (vrt_render_geometry_batch); every frame gets its own planes, kept in `batch`
+    const std::vector<GeometryBuffer>& recordBatch(const std::vector<vrt_push>& pushes, const vrt_shard* shard = nullptr)
+    {
+        auto res = settings->renderResolution();
+        size_t n = (size_t)res[0] * res[1];
+        while (batch.size() < pushes.size()) {
+            GeometryBuffer g;
+            g.color = std::make_shared<DeviceBuffer<uint8_t>>(engine, n * 4); g.mask = std::make_shared<DeviceBuffer<uint8_t>>(engine, n);
+            g.depth = std::make_shared<DeviceBuffer<float>>(engine, n); g.motion = std::make_shared<DeviceBuffer<float>>(engine, n * 2);
+            g.position = std::make_shared<DeviceBuffer<float>>(engine, n * 4); g.normal = std::make_shared<DeviceBuffer<int8_t>>(engine, n * 4);
+            g.width = res[0]; g.height = res[1];
+            batch.push_back(g);
+        }
+        std::vector<vrt_frame> frames(pushes.size());
+        for (size_t k = 0; k < pushes.size(); k++) {
+            vrt_frame f{}; const GeometryBuffer& g = batch[k];
+            f.color8 = g.color->ptr; f.depth = g.depth->ptr; f.motion = g.motion->ptr; f.mask8 = g.mask->ptr; f.position = g.position->ptr; f.normal8 = g.normal->ptr;
+            frames[k] = f;
+        }
+        vrt_settings st = settings->toC();
+        check(vrt_render_geometry_batch(engine->ctx, scene->handle, (int32_t)pushes.size(), pushes.data(), &st, frames.data(), shard));
+        return batch;
+    }
 private:
     std::shared_ptr<Engine> engine; std::shared_ptr<VoxelRenderSettings> settings; std::shared_ptr<VoxelScene> scene; GeometryBuffer gb;
+    std::vector<GeometryBuffer> batch;
 };
 
 class DenoiserStage {
