@@ -729,26 +729,28 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
     const int y0 = whole ? (r0 < P.H ? r0 : -1) : strip_row(P.sh, P.extend, r0, P.H);
     if (y0 < 0) return;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    // staging: thread (lx, ly) loads columns lx and (for lx < 2R) 64 + lx of rows ly, ly + 4, ... of the haloed tile
+    // staging: texel t = threadIdx.x + 256 k of the haloed tile, k = 0, 1, ... -- every thread gets the same number of
+    // texels (+-1); (cx, cy) = (t % RW, t / RW) is kept without divisions: RW is 66..74, so threadIdx.x / RW is 0..3
     {
-        const int ncol = lx < 2 * R ? 2 : 1;
-        for (int k = 0; k < ncol; k++) {
-            const int cx = k == 0 ? lx : 64 + lx;
-            int x = x0 - R + cx;
+        const int t0 = (int)threadIdx.x;
+        int cy = (t0 >= RW ? 1 : 0) + (t0 >= 2 * RW ? 1 : 0) + (t0 >= 3 * RW ? 1 : 0);
+        int cx = t0 - cy * RW;
+        const int dy = 256 >= 3 * RW + RW ? 4 : 3;             // 256 / RW (RW <= 64: 4 never happens; RW in 66..74: 3)
+        const int dx = 256 - dy * RW;
+        for (int t = t0; t < NP; t += 256) {
+            int x = x0 - R + cx, y = y0 - R + cy;
             x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
-            for (int cy = ly; cy < RH; cy += 4) {
-                int y = y0 - R + cy;
-                y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-                const size_t i = (size_t)y * (size_t)P.W + (size_t)x;
-                const int t = cy * RW + cx;
-                const uchar4 c = reinterpret_cast<const uchar4*>(P.color_in)[i];
-                lc[t] = make_float4(decode_unorm8(c.x), decode_unorm8(c.y), decode_unorm8(c.z), decode_unorm8(c.w));
-                if (!PHI_INF) {                               // pass 0 weighs every tap 1: only the colour is ever read
-                    const char4 n = reinterpret_cast<const char4*>(P.normal)[i];
-                    ln[t] = make_float4(decode_snorm8(n.x), decode_snorm8(n.y), decode_snorm8(n.z), decode_snorm8(n.w));
-                    lp[t] = reinterpret_cast<const float4*>(P.position)[i];
-                }
+            y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+            const size_t i = (size_t)y * (size_t)P.W + (size_t)x;
+            const uchar4 c = reinterpret_cast<const uchar4*>(P.color_in)[i];
+            lc[t] = make_float4(decode_unorm8(c.x), decode_unorm8(c.y), decode_unorm8(c.z), decode_unorm8(c.w));
+            if (!PHI_INF) {                                   // pass 0 weighs every tap 1: only the colour is ever read
+                const char4 n = reinterpret_cast<const char4*>(P.normal)[i];
+                ln[t] = make_float4(decode_snorm8(n.x), decode_snorm8(n.y), decode_snorm8(n.z), decode_snorm8(n.w));
+                lp[t] = reinterpret_cast<const float4*>(P.position)[i];
             }
+            cx += dx; cy += dy;
+            if (cx >= RW) { cx -= RW; cy++; }
         }
     }
     __syncthreads();
