@@ -176,6 +176,12 @@ def main():
             cpu = {"value": round(W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
                    "sample": f"one full {W}x{H} frame of the same workload (pose 0), scalar C oracle, rows interleaved over {ncores} threads",
                    "hit_ids_match_gpu": same}
+            # one thread on a band of the same frame (every 8th row group would bias towards sky; a centred band does not)
+            r0, r1 = H // 2 - 60, H // 2 + 60
+            c1 = time.perf_counter()
+            oracle.render_band(osn, pushes[0], oracle.params_from(st.to_c()), r0, r1, planes=["hit_id"], nthreads=1)
+            cpu["single_thread"] = {"value": round(W * (r1 - r0) / (time.perf_counter() - c1) / 1e6, 3), "unit": "Mrays/s",
+                                    "sample": f"rows {r0}..{r1 - 1} of the same frame, one thread"}
         out = {"metric": "Mrays/sec at 1080p treehouse.vox; achieved HBM GB/s vs MI355X peak",
                "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
