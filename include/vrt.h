@@ -64,7 +64,7 @@ typedef struct vrt_push {
 #define VRT_TRAVERSAL_DENSE   1   /* one R8 fetch per DDA iteration (voxel_volume.frag:157), fetched 4 iterations ahead */
 #define VRT_TRAVERSAL_BITMASK 2   /* solid test on 4^3 occupancy words (L2) + 16^3 / 64^3 summaries staged in LDS */
 #define VRT_TRAVERSAL_JUMP    3   /* BITMASK + exact closed-form jumps across empty pyramid cells */
-#define VRT_TRAVERSAL_DF      4   /* octant clearance agreed per wave by ballot; ALU-only runs between fetches */
+#define VRT_TRAVERSAL_DF      4   /* octant clearance, its minimum over the wave agreed by a DPP reduction; ALU-only runs between look-ups */
 #define VRT_TRAVERSAL_DFJ     5   /* DF with the long runs (clearance >= 12) done per lane in closed form (JUMP's integer form) */
 
 #define VRT_FLAG_SPLIT_KERNELS 4u /* trace secondary rays in a second kernel (K2) over the compacted hit list instead of inside K1 */

@@ -4,12 +4,14 @@
 //   k_primary<...>    K1: per-pixel ray generation + Amanatides-Woo DDA + G-buffer write
 //                     (voxel_volume.frag:309-346, :109-196 of the reference)
 //   k_shade<...>      K2: AO / shadow / mirror-bounce rays + shading (voxel_volume.frag:205-307)
-//   k_denoise         K3: one a-trous cross-bilateral pass (denoiser.frag:38-73)
-//   k_rows            strip pack / unpack for the multi-GPU gather and halo exchange
+//   k_denoise(_lds)   K3: one a-trous cross-bilateral pass (denoiser.frag:38-73)
+//   k_rows(_batch)    strip pack / unpack for the multi-GPU gather and halo exchange
+//   k_blit, k_accumulate, k_resolve   presentation / temporal rows (blit.frag, the FSR2 stand-in)
 //
-// One workgroup = 256 threads = one 16x16 screen tile; each of its 4 waves owns an 8x8 pixel block so
-// that the 64 rays of a wave stay spatially coherent.  Rays are generated in-kernel from the 96-byte
-// push-constant block (no ray buffers).  No MFMA: nothing here is a dense contraction.
+// A wave owns an 8x8 pixel block so that its 64 rays stay spatially coherent; the default (clearance-field)
+// traversal runs one wave per workgroup, the LDS-staged ones 16x16 tiles of four waves.  Rays are generated in-kernel
+// from the 96-byte push-constant block (no ray buffers); a launch covers up to 8 frames.  No MFMA: nothing here is a
+// dense contraction.
 //
 // All arithmetic follows vrt_spec.h (fp32, -ffp-contract=off); the DDA state (sideDist, mapPos, mask)
 // is advanced with exactly the additions of voxel_volume.frag:164-170 in every traversal mode, so hit

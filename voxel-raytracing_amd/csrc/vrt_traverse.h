@@ -4,7 +4,7 @@
 //   DENSE    one R8 fetch per DDA iteration (the literal shader loop)
 //   BITMASK  same iterations; the solid test reads the 4^3 occupancy word cached in registers and the
 //            16^3 summary (LDS) before touching global memory; the R8 id is fetched once, at the hit
-//   DF       the wave agrees by ballot on a number of iterations no lane needs a memory test for (distance
+//   DF       the wave agrees (one DPP min-reduction) on a number of iterations no lane needs a memory test for (distance
 //            field clearance) and runs them as pure ALU stepping; one gather per run instead of per iteration
 //   JUMP     BITMASK inside occupied 4^3 cells; across EMPTY pyramid cells (4^3 / 16^3 / 64^3) one iteration
 //            replaces all the DDA iterations up to the cell's exit -- exactly (see "exact jumps" below)
@@ -464,7 +464,7 @@ VRT_HD uint32_t wave_min_vote(uint32_t k)
 // the voxel as its corner and extends towards the octant's signs.  A ray only ever moves towards the signs of
 // its direction, at most one voxel per axis per DDA iteration, so its next k-1 iterations stay inside that cube:
 // no memory test is needed for them (unlike an isotropic distance field, the clearance of a ray LEAVING a
-// surface is large at once).  Voxels outside the volume count as solid, which bounds a run at the walls.  The lanes of a wave agree by ballot on the smallest clearance among them and run
+// surface is large at once).  Voxels outside the volume count as solid, which bounds a run at the walls.  The lanes of a wave agree on the smallest clearance among them (wave_min_vote) and run
 // that many iterations of pure ALU stepping -- the same fp32 additions as the shader, hence bit-identical
 // results -- then look at memory again.  Neighbouring rays have similar clearances, so the wave-wide minimum
 // costs little.  Finished lanes are masked off; the votes see live lanes only.
