@@ -8,7 +8,9 @@
  * returns the thread-local message (the reference throws std::runtime_error, app.cpp:21-25).
  *
  * Threading: one vrt_ctx per host thread / per GPU; calls on one context are serialised on its HIP
- * stream (the reference is strictly single-threaded, engine.cpp:28-46).  All image pointers in
+ * stream (the reference is strictly single-threaded, engine.cpp:28-46).  Frames in flight
+ * (MAX_FRAMES_IN_FLIGHT, engine.hpp:19): one context per frame slot; contexts of one device run
+ * concurrently and may share a vrt_scene, which is read-only while rendering.  All image pointers in
  * vrt_frame are DEVICE pointers owned by the caller (or allocated with vrt_device_alloc).
  * There is no CPU fallback: without a HIP device every compute call fails with VRT_ERR_NO_DEVICE.
  */
