@@ -56,12 +56,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a box with ONE GPU: VRT_BENCH_BACKEND=gloo VRT_BENCH_DEVICE=0 makes every rank
+    # use cuda:0 and sends the gather through host memory (numbers from such a run are not benchmark results)
+    backend = os.environ.get("VRT_BENCH_BACKEND", "nccl")
+    if "VRT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["VRT_BENCH_DEVICE"])
     if world != args.gpus:
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     engine = vrt.Engine(local_rank)
     W, H, NV = args.width, args.height, args.volume
@@ -81,7 +89,7 @@ def main():
     for f in range(F):                                        # camera + push constants per pose, marshalled once
         renderer.camera.position = poses[f]
         pushes.append(renderer.push_constants())
-    sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world)
+    sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world, host_staged=(backend != "nccl"))
     launches_per_step = (F + 7) // 8                          # K1 launches per rank and step
 
     overlap = os.environ.get("VRT_SYNC_GATHER", "0") != "1"
@@ -116,7 +124,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=engine.torch_device)
+        t = torch.tensor([dt], dtype=torch.float64, device=engine.torch_device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -144,6 +152,15 @@ def main():
         b_alg = (sum(S_frames) + frames_per_launch * W * H * B_OUT) / world
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         tm = engine.last_timings()
+        # N > 1: the frames assembled on rank 0 from everybody's strips must be the frames one GPU renders alone
+        assembled_ok = None
+        if world > 1:
+            chk = vrt.GeometryStage(engine, st, scene)
+            assembled_ok = True
+            for f in (0, F - 1):
+                alone = chk.record(pushes[f]).color
+                engine.synchronize()
+                assembled_ok = assembled_ok and bool((sb.finals[f] == alone).all().item())
         # HBM bytes per K1 launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
         # this same command; tools/pmc_summary.py -> profiles/*_k_primary_pmc.json).  Counters cannot be read from inside
         # the process, so the committed summary is quoted, and only for the configuration it was collected on.
@@ -190,7 +207,7 @@ def main():
                                       f"(BASELINE configs[1]); {F} frame(s)/step ({F // world} per GPU, consecutive poses, one K1 launch per 8), "
                                       f"16-row strips round-robin over {world} GPU(s)"
                                       + (", one RCCL gather/step" if world > 1 else ""),
-                          "traversal": args.traversal, "frames_per_step": F, "hit_fraction": round(hit_frac[0], 4), "bytes_out_per_px": B_OUT,
+                          "traversal": args.traversal, "frames_per_step": F, "assembled_frames_match_single_gpu": assembled_ok, "hit_fraction": round(hit_frac[0], 4), "bytes_out_per_px": B_OUT,
                           "device": engine.device_info()[0]},
                "roofline": roofline, "cpu_baseline": cpu}
         log(f"timings of last call: {tm}")

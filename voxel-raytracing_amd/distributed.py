@@ -209,9 +209,10 @@ class ShardedBatch:
     of all of them (vrt_render_geometry_batch), one strip-pack launch, ONE gather of the whole batch to rank 0, one unpack
     launch per 64 (frame, source) pairs there.  Geometry only (the denoiser needs the halo exchange of ShardedFrame)."""
 
-    def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None):
+    def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False):
         import torch
         self.stage, self.F = stage, int(n_frames)
+        self.host_staged = bool(host_staged)       # gather through host memory (gloo rehearsal of the N > 1 path on one GPU)
         self.rank, self.nranks, self.group = int(rank), int(nranks), group
         W, H = stage._settings.renderResolution()
         self.W, self.H = W, H
@@ -275,6 +276,12 @@ class ShardedBatch:
         stream, ordered after the pack by an event)."""
         import torch.distributed as dist
         bufs = self.recv_buffers() if self.rank == 0 else None
+        if getattr(self, "host_staged", False):                  # rehearsal: device -> host, host gather, host -> device
+            src = self.packed.cpu()
+            hb = [src.new_empty(src.shape) for _ in range(self.nranks)] if self.rank == 0 else None
+            self._work = dist.gather(src, gather_list=hb, dst=0, group=self.group, async_op=True)
+            self._host = (src, hb, bufs)
+            return
         self._work = dist.gather(self.packed, gather_list=bufs, dst=0, group=self.group, async_op=True)
 
     def finish(self):
@@ -285,6 +292,10 @@ class ShardedBatch:
             return None
         w.wait()
         self._work = None
+        if getattr(self, "host_staged", False) and self.rank == 0:
+            _, hb, bufs = self._host
+            for b, h in zip(bufs, hb):
+                b.copy_(h)
         return self.assemble() if self.rank == 0 else None
 
     def step(self, pushes, overlap: bool = True):
