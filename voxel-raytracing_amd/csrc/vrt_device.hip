@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     trace_ray<TRAV>(s, occ, start, dir, P.st.max_steps, h, r);
     bool hit = h.material != 0;
 
-    const vrt_frame& f = S.fr;
+    const vrt_frame f = S.fr;                 // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store
     float depth = 0.0f;
     if (hit) depth = len3(mk3(h.pos.x - start.x, h.pos.y - start.y, h.pos.z - start.z));
     if (f.depth) f.depth[i] = depth;
