@@ -1,0 +1,21 @@
+"""Rays traced per frame (primary + AO + shadow + bounce) and step counts for BASELINE configs 2 / 3 and the reference defaults."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import voxel_raytracing_amd as vrt
+eng = vrt.Engine(0)
+vol = vrt.synthetic.treehouse(256, seed=2)
+sc = vrt.VoxelScene.from_dense(eng, vol, vrt.synthetic.default_palette(metallic_ids=range(200, 256)), sky=vrt.synthetic.sky_gradient(512, 256), noise=vrt.synthetic.blue_noise_standin(512))
+res = (1920, 1080)
+pos0, yaw, pitch = vrt.synthetic.default_camera_for(256, 256, 256)
+push = vrt.make_push(vrt.CameraController(position=pos0, yaw=yaw, pitch=pitch), (256, 256, 256), res)
+def cfg(ao, sh, b):
+    st = vrt.VoxelRenderSettings(targetResolution=res); st.fsrSetttings.enable = False
+    st.occlusionSettings.numSamples = ao; st.traceSettings.shadows = sh; st.traceSettings.maxReflections = b
+    return st
+for name, st in (("config 2 (primary only)", cfg(0, False, 0)), ("config 3 (+shadow)", cfg(0, True, 0)), ("reference defaults", cfg(4, True, 5))):
+    st.traceSettings.traversal = vrt.TRAVERSAL_BITMASK                     # exact step counts
+    gb = vrt.GeometryStage(eng, st, sc, debug_planes=True).record(push)
+    eng.synchronize()
+    rays = int(gb.rays_total.to(torch.int64).sum().item()); steps = int(gb.steps_total.to(torch.int64).sum().item())
+    print(f"{name:26s} rays/frame {rays:10d} ({rays / (res[0] * res[1]):.2f} per px)  DDA steps/frame {steps:12d}", flush=True)
