@@ -191,7 +191,24 @@ __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 s
 // shading helpers
 // ---------------------------------------------------------------------------------------------
 
-struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; };   // pc: the push block of the pixel's frame
+// UNORM8 / SNORM8 code -> float: q0 = c * r, q = fma(fma(-D, q0, c), r, q0) with r = RN(1 / D) equals the IEEE quotient c / D
+// for every one of the 256 codes (checked exhaustively in tests/test_denoise_decode.py): 3 VALU ops instead of ~11.
+__device__ __forceinline__ float decode_unorm8(uint32_t c)
+{
+    const float r = 1.0f / 255.0f;
+    float cf = (float)c, q0 = cf * r;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, q0, cf), r, q0);
+}
+__device__ __forceinline__ float decode_snorm8(int32_t c)
+{
+    const float r = 1.0f / 127.0f;
+    float cf = (float)c, q0 = cf * r;
+    return fmaxf(__builtin_fmaf(__builtin_fmaf(-127.0f, q0, cf), r, q0), -1.0f);
+}
+
+// pc: the push block of the pixel's frame; noise: the pixel's blue-noise texel, decoded on first use (it is the same for
+// every AO sample and every bounce of the pixel)
+struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; f3 noise; bool have_noise; };
 
 // skyColor, voxel_volume.frag:98-105
 __device__ __forceinline__ f3 sky_color(const DevScene& s, f3 d)
@@ -204,19 +221,23 @@ __device__ __forceinline__ f3 sky_color(const DevScene& s, f3 d)
 }
 
 // fragmentNoiseSeq + randomDir, voxel_volume.frag:80-95
-__device__ __forceinline__ f3 random_dir(const DevScene& s, const vrt_push& pc, const PixCtx& c, uint32_t num)
+__device__ __forceinline__ f3 random_dir(const DevScene& s, const vrt_push& pc, PixCtx& c, uint32_t num)
 {
     uint32_t offset = num * 32u + pc.frame % 32u;
     const float g = 1.22074408460575947536f;
     const float a0 = 1.0f / g, a1 = 1.0f / (g * g), a2 = 1.0f / ((g * g) * g);
-    float pxf = ((float)c.px + 0.5f) / 512.0f + 0.5f;
-    float pyf = ((float)c.py + 0.5f) / 512.0f + 0.5f;
-    uint32_t tx = wrap_texel(pxf, s.noise_w), ty = wrap_texel(pyf, s.noise_h);
-    const uchar4 t = reinterpret_cast<const uchar4*>(s.noise)[(size_t)ty * s.noise_w + tx];
+    if (!c.have_noise) {
+        float pxf = ((float)c.px + 0.5f) / 512.0f + 0.5f;
+        float pyf = ((float)c.py + 0.5f) / 512.0f + 0.5f;
+        uint32_t tx = wrap_texel(pxf, s.noise_w), ty = wrap_texel(pyf, s.noise_h);
+        const uchar4 t = reinterpret_cast<const uchar4*>(s.noise)[(size_t)ty * s.noise_w + tx];
+        c.noise = mk3(decode_unorm8(t.x), decode_unorm8(t.y), decode_unorm8(t.z));          // = t / 255.0f, exactly
+        c.have_noise = true;
+    }
     float fo = (float)offset;
-    float n0 = (float)t.x / 255.0f + fo * a0;
-    float n1 = (float)t.y / 255.0f + fo * a1;
-    float n2 = (float)t.z / 255.0f + fo * a2;
+    float n0 = c.noise.x + fo * a0;
+    float n1 = c.noise.y + fo * a1;
+    float n2 = c.noise.z + fo * a2;
     n0 = n0 - floorf(n0); n1 = n1 - floorf(n1); n2 = n2 - floorf(n2);
     return normalize3(mk3(n0 * 2.0f - 1.0f, n1 * 2.0f - 1.0f, n2 * 2.0f - 1.0f));
 }
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (MODE != 0) {
         f3 col;
         if (hit) {
-            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &S.pc;
+            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &S.pc; c.have_noise = false;
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 col = color_main_ray<TRAV>(P, occ, c, h);
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     h.pos = mk3(__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z));
     uint32_t mask = (rec.w >> 8) & 7u;
     int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;
-    PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &P.slot[0].pc;
+    PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &P.slot[0].pc; c.have_noise = false;
     h.normal = hit_normal(mask, sx, sy, sz);
     f3 col = color_main_ray<TRAV>(P, occ, c, h);
     const vrt_frame& f = P.slot[0].fr;
@@ -596,18 +617,6 @@ const char* primary_kernel_name(int traversal, int fused, int occ_lds)
 
 struct Guides { float c[4], n[4], p[4]; };
 
-__device__ __forceinline__ float decode_unorm8(uint32_t c)
-{
-    const float r = 1.0f / 255.0f;
-    float cf = (float)c, q0 = cf * r;
-    return __builtin_fmaf(__builtin_fmaf(-255.0f, q0, cf), r, q0);
-}
-__device__ __forceinline__ float decode_snorm8(int32_t c)
-{
-    const float r = 1.0f / 127.0f;
-    float cf = (float)c, q0 = cf * r;
-    return fmaxf(__builtin_fmaf(__builtin_fmaf(-127.0f, q0, cf), r, q0), -1.0f);
-}
 
 __device__ __forceinline__ void texel_guides(const DenoiseParams& P, int x, int y, Guides& g)
 {
