@@ -16,9 +16,16 @@ HDRS = [os.path.join(ROOT, "voxel-raytracing_amd", "csrc", h) for h in ("vrt_tra
 
 @pytest.fixture(scope="module")
 def th():
-    if not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(p) for p in [SRC] + HDRS):
+    lib = LIB
+    if os.environ.get("VRT_TH_SANITIZE") == "1":
+        # AddressSanitizer + UBSan build of the same code (CPU only; run with LD_PRELOAD=$(gcc -print-file-name=libasan.so)
+        # ASAN_OPTIONS=detect_leaks=0): out-of-bounds reads of the padded clearance fields, the occupancy pyramid, ...
+        lib = LIB.replace(".so", "_san.so")
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=undefined", "-fPIC", "-shared", "-o", lib, SRC])
+    elif not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(p) for p in [SRC] + HDRS):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB, SRC])
-    l = C.CDLL(LIB)
+    l = C.CDLL(lib)
     l.th_create.restype = C.c_void_p
     l.th_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     l.th_destroy.argtypes = [C.c_void_p]
