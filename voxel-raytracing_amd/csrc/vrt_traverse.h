@@ -428,7 +428,15 @@ VRT_HD uint32_t wave_min_u6(uint32_t k)
 VRT_HD uint32_t wave_min_vote(uint32_t k)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (__ballot(true) == ~0ull) {
+    // Half of all look-ups end with a clearance of 1 somewhere in the wave, another quarter with 2 or 3: one compare
+    // each answers those before the 7-op reduction is needed (votes are >= 1; VRT_VOTE_DONE matches none of them).
+    if (__ballot(k == 1u) != 0ull) return 1u;
+    const bool full = __ballot(true) == ~0ull;
+    if (!full) {                                               // secondary rays of a partly hit wave: the reduction below is
+        if (__ballot(k == 2u) != 0ull) return 2u;              // the 6-vote binary search, worth two more shortcuts
+        if (__ballot(k == 3u) != 0ull) return 3u;
+    }
+    if (full) {
         uint32_t v = k, total;
         asm volatile("s_nop 1\n\t"
                      "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
