@@ -9,9 +9,13 @@ A "step" is one pass of the hot path over one batch of synthetic input: a batch 
 F = --frames-per-gpu, default 8; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips
 that are dealt round-robin to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch per
 8 frames (vrt_render_geometry_batch: the next frame's tiles are dispatched while the previous frame drains), packs
-them with one launch, and the batch is gathered to rank 0 with ONE RCCL gather per step and assembled there with one
-launch per 64 (frame, source) pairs.  Per-GPU work per step is therefore F frames' worth of rays at every N ("weak"
-scaling); value = total primary rays of all ranks / wall time.  At N = 1 there is no collective and no copy.
+them, and ONE RCCL collective per step moves the strips to where the frames are assembled: frame block b (F frames) is
+gathered to rank b, the N gathers issued as a single all-to-all so that every GPU receives over all of its xGMI links
+(VRT_ASSEMBLE=root: everything to rank 0 with one dist.gather instead -- bound by rank 0's inbound links).  The strip
+assignment is rotated per block, so every rank traces the same number of rows per step although 1080 rows are 67.5
+strips.  The collective of a step runs while the next step is traced.  Per-GPU work per step is therefore F frames'
+worth of rays at every N ("weak" scaling); value = total primary rays of all ranks / wall time.  At N = 1 there is no
+collective and no copy.
 
 Workload = BASELINE.json configs[1]: treehouse stand-in (synthetic:treehouse(seed=2), 256^3 -- the real
 treehouse.vox is a git-LFS pointer in the reference checkout), 1920x1080, primary rays only.
@@ -89,18 +93,21 @@ def main():
     for f in range(F):                                        # camera + push constants per pose, marshalled once
         renderer.camera.position = poses[f]
         pushes.append(renderer.push_constants())
-    sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world, host_staged=(backend != "nccl"))
-    launches_per_step = (F + 7) // 8                          # K1 launches per rank and step
+    assemble_on = os.environ.get("VRT_ASSEMBLE", "owners")     # where finished frames end up: "owners" | "root"
+    sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world, host_staged=(backend != "nccl"),
+                                      assemble_on=assemble_on)
+    fpg = F // world
+    launches_per_step = world * ((fpg + 7) // 8) if sb.owners else (F + 7) // 8    # K1 launches per rank and step
 
     overlap = os.environ.get("VRT_SYNC_GATHER", "0") != "1"
 
     def step():
-        # K1 over this rank's strips of the F frames, then pack + ONE RCCL gather (+ assembly on rank 0); the gather of a
-        # step runs while the next step is traced (VRT_SYNC_GATHER=1: strictly one after the other)
+        # K1 over this rank's strips of the F frames, then pack + ONE RCCL collective (+ assembly at the receivers); the
+        # collective of a step runs while the next step is traced (VRT_SYNC_GATHER=1: strictly one after the other)
         sb.step(pushes, overlap)
 
     def barrier():
-        sb.finish()                                           # the gather still in flight, and its assembly on rank 0
+        sb.finish()                                           # the collective still in flight, and the assembly of its frames
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -132,6 +139,22 @@ def main():
     value = rays_per_step * args.steps / dt / 1e6
     kern_ms = float(marks[0].elapsed_time(marks[-1])) / (args.steps * launches_per_step)   # per K1 launch
 
+    # N > 1: the frames assembled from everybody's strips must be the frames one GPU renders alone (checked on every rank
+    # that holds finished frames, outside the timed region)
+    assembled_ok = None
+    if world > 1:
+        mine = list(sb.owned_frames())
+        good = 1
+        if mine:
+            chk = vrt.GeometryStage(engine, st, scene)
+            for j in (0, len(mine) - 1):
+                alone = chk.record(pushes[mine[j]]).color
+                engine.synchronize()
+                good = good and int(bool((sb.finals[j] == alone).all().item()))
+        t = torch.tensor([good], dtype=torch.int32, device=engine.torch_device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        assembled_ok = bool(t.item())
+
     out = None
     if rank == 0:
         # ---- algorithmic bytes of one K1 launch: S fetches (1 B each) + W*H*B_out ----
@@ -152,15 +175,6 @@ def main():
         b_alg = (sum(S_frames) + frames_per_launch * W * H * B_OUT) / world
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         tm = engine.last_timings()
-        # N > 1: the frames assembled on rank 0 from everybody's strips must be the frames one GPU renders alone
-        assembled_ok = None
-        if world > 1:
-            chk = vrt.GeometryStage(engine, st, scene)
-            assembled_ok = True
-            for f in (0, F - 1):
-                alone = chk.record(pushes[f]).color
-                engine.synchronize()
-                assembled_ok = assembled_ok and bool((sb.finals[f] == alone).all().item())
         # HBM bytes per K1 launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
         # this same command; tools/pmc_summary.py -> profiles/*_k_primary_pmc.json).  Counters cannot be read from inside
         # the process, so the committed summary is quoted, and only for the configuration it was collected on.
@@ -206,7 +220,8 @@ def main():
                "config": {"workload": f"synthetic:treehouse(seed=2) {NV}^3 stand-in for treehouse.vox, {W}x{H}, primary rays only "
                                       f"(BASELINE configs[1]); {F} frame(s)/step ({F // world} per GPU, consecutive poses, one K1 launch per 8), "
                                       f"16-row strips round-robin over {world} GPU(s)"
-                                      + (", one RCCL gather/step" if world > 1 else ""),
+                                      + ((", one RCCL all-to-all/step (frame block b assembled on rank b), strip assignment rotated per block"
+                                          if sb.owners else ", one RCCL gather/step to rank 0") if world > 1 else ""),
                           "traversal": args.traversal, "frames_per_step": F, "assembled_frames_match_single_gpu": assembled_ok, "hit_fraction": round(hit_frac[0], 4), "bytes_out_per_px": B_OUT,
                           "device": engine.device_info()[0]},
                "roofline": roofline, "cpu_baseline": cpu}

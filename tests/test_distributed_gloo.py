@@ -88,9 +88,10 @@ def test_gather_and_halo_gloo(world, strip_rows):
     assert q.get(timeout=5) == 1
 
 
-def _batch_worker(rank, world, port, q):
-    """ShardedBatch's step protocol (bench.py's N > 1 path) with numpy stand-ins for the three device calls: the gather of
-    step k must deliver step k's frames even though step k + 1 is "rendered" before it is completed."""
+def _batch_worker(rank, world, port, q, mode="root"):
+    """ShardedBatch's step protocol (bench.py's N > 1 path) with numpy stand-ins for the three device calls: the collective
+    of step k must deliver step k's frames even though step k + 1 is "rendered" before it is completed.  mode "root": gather
+    to rank 0; "owners": frame block b to rank b by one all-to-all, the strip assignment rotated per block."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -98,7 +99,10 @@ def _batch_worker(rank, world, port, q):
     import voxel_raytracing_amd as vrt
     dist.init_process_group("gloo", rank=rank, world_size=world)
     D = vrt.distributed
-    W, H, F, SR = 40, 70, 3, 16
+    owners = mode == "owners"
+    W, H, SR = 40, 70, 16
+    FB = 2
+    F = world * FB if owners else 3
     prow = D.packed_rows(H, world, SR)
     rmap = [D.packed_row_map(H, r, world, SR) for r in range(world)]
 
@@ -108,30 +112,39 @@ def _batch_worker(rank, world, port, q):
 
     sb = D.ShardedBatch.__new__(D.ShardedBatch)                 # the protocol only: no engine, no kernels
     sb.rank, sb.nranks, sb.group, sb.F, sb.W, sb.H, sb.strip_rows = rank, world, None, F, W, H, SR
+    sb.owners, sb.rotate, sb.FB, sb.host_staged = owners, owners, FB, False
     sb.packed = torch.zeros((F, prow, W, 4), dtype=torch.uint8)
     sb._root = None
     state = {"step": -1}
-    if rank == 0:
-        sb.finals = torch.zeros((F, H, W, 4), dtype=torch.uint8)
+    mine_frames = list(sb.owned_frames())
+    assert mine_frames == (list(range(rank * FB, (rank + 1) * FB)) if owners else (list(range(F)) if rank == 0 else []))
+    if mine_frames:
+        sb.finals = torch.zeros((len(mine_frames), H, W, 4), dtype=torch.uint8)
     sb.render = lambda pushes: state.__setitem__("step", state["step"] + 1)
     def pack():
         t = truth(state["step"])
-        own = D.owned_rows(H, rank, world, SR)
-        mine = np.zeros_like(t); mine[:, own] = t[:, own]      # a rank holds its own rows only
         for f in range(F):
-            sb.packed[f] = torch.from_numpy(D.pack_np(mine[f], rmap[rank]))
+            vr = sb.virtual_rank(rank, f // FB) if owners else rank
+            own = D.owned_rows(H, vr, world, SR)
+            mine = np.zeros_like(t[f]); mine[own] = t[f][own]   # a rank holds its own rows only
+            sb.packed[f] = torch.from_numpy(D.pack_np(mine, rmap[vr]))
         return sb.packed
     sb.pack = pack
     def recv_buffers():
         if sb._root is None:
-            sb._root = ([torch.empty_like(sb.packed) for _ in range(world)],)
+            sb._root = (torch.empty_like(sb.packed) if owners else [torch.empty_like(sb.packed) for _ in range(world)],)
         return sb._root[0]
     sb.recv_buffers = recv_buffers
     def assemble():
-        out = np.zeros((F, H, W, 4), np.uint8)
-        for src, b in enumerate(sb._root[0]):
-            for f in range(F):
-                D.unpack_np(b[f].numpy(), out[f], rmap[src])
+        out = np.zeros((len(mine_frames), H, W, 4), np.uint8)
+        if owners:
+            for src in range(world):
+                for j in range(FB):
+                    D.unpack_np(sb._root[0][src * FB + j].numpy(), out[j], rmap[sb.virtual_rank(src, rank)])
+        else:
+            for src, b in enumerate(sb._root[0]):
+                for f in range(F):
+                    D.unpack_np(b[f].numpy(), out[f], rmap[src])
         sb.finals.copy_(torch.from_numpy(out))
         return sb.finals
     sb.assemble = assemble
@@ -141,14 +154,16 @@ def _batch_worker(rank, world, port, q):
         out = sb.step(None, overlap=True)
         got.append(None if out is None else out.numpy().copy())
     last = sb.finish()
-    if rank == 0:
-        ok = got[0] is None and all((got[k] == truth(k - 1)).all() for k in (1, 2, 3)) and bool((last.numpy() == truth(3)).all())
+    if mine_frames:
+        ok = got[0] is None and all((got[k] == truth(k - 1)[mine_frames]).all() for k in (1, 2, 3)) and bool((last.numpy() == truth(3)[mine_frames]).all())
     else:
         ok = all(g is None for g in got) and last is None
     ok = ok and sb.finish() is None                              # nothing left in flight
     out = sb.step(None, overlap=False)                           # synchronous form: this step's frames at once
-    if rank == 0:
-        ok = ok and bool((out.numpy() == truth(4)).all())
+    if mine_frames:
+        ok = ok and bool((out.numpy() == truth(4)[mine_frames]).all())
+    else:
+        ok = ok and out is None
     t = torch.tensor([1 if ok else 0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -157,13 +172,14 @@ def _batch_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["root", "owners"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_batch_step_protocol_gloo(world):
+def test_sharded_batch_step_protocol_gloo(world, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

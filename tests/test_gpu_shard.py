@@ -145,3 +145,45 @@ def test_sharded_batch_assembles_to_the_unsharded_frames(vrt, engine):
     for f in range(F):
         assert (finals[f] == ref[f]).all(), f
     assert any((ref[f] != ref[0]).any().item() for f in range(1, F))
+
+
+@pytest.mark.parametrize("rotate", [True, False])
+def test_sharded_batch_owner_blocks_assemble_to_the_unsharded_frames(vrt, engine, rotate):
+    """ShardedBatch(assemble_on="owners"): frame block b ends up on rank b.  The all-to-all is replaced by device copies
+    (chunk d of rank s's send buffer -> chunk s of rank d's receive buffer); 136 rows = 8.5 strips over 3 ranks, so the
+    ranks own different numbers of rows and the rotation of the strip assignment per block matters."""
+    import torch
+    vol = vrt.synthetic.treehouse(48, seed=6)
+    sc = vrt.VoxelScene.from_dense(engine, vol, vrt.synthetic.default_palette(), sky=vrt.synthetic.sky_gradient(64, 32))
+    res, N, FB = (208, 136), 3, 2
+    F = N * FB
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    pushes = [vrt.make_push(vrt.CameraController(position=(24.0 + f, 25.0, -40.0 + 2.0 * f)), (48, 48, 48), res) for f in range(F)]
+    ref = [g.color.clone() for g in vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, 0, 1).step(pushes)]
+    ranks = [vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, r, N, assemble_on="owners", rotate=rotate)
+             for r in range(N)]
+    recv = [sb.recv_buffers() for sb in ranks]
+    for s, sb in enumerate(ranks):
+        sb.render(pushes)
+        sent = sb.pack()
+        for d in range(N):
+            recv[d][s * FB:(s + 1) * FB].copy_(sent[d * FB:(d + 1) * FB])
+    rows = []
+    for d, sb in enumerate(ranks):
+        finals = sb.assemble()
+        engine.synchronize()
+        assert list(sb.owned_frames()) == list(range(d * FB, (d + 1) * FB))
+        for j, f in enumerate(sb.owned_frames()):
+            assert (finals[j] == ref[f]).all(), (d, f)
+        # rows this rank traces per step: equal over the ranks only with the rotation
+        rows.append(sum(len(vrt.distributed.owned_rows(res[1], sb.virtual_rank(d, b), N, sb.strip_rows)) for b in range(N)))
+    assert sum(rows) == N * res[1]
+    assert (max(rows) == min(rows)) == rotate
+
+
+def test_sharded_batch_owner_blocks_need_an_even_batch(vrt, engine):
+    vol = vrt.synthetic.treehouse(32, seed=1)
+    sc = vrt.VoxelScene.from_dense(engine, vol, vrt.synthetic.default_palette())
+    st = vrt.VoxelRenderSettings.primary_only((64, 48))
+    with pytest.raises(ValueError):
+        vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), 5, 0, 3, assemble_on="owners")

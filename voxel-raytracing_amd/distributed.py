@@ -3,7 +3,8 @@
 One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" on CPU for the tests).
 The frame is cut into horizontal strips of `strip_rows` rows; strip s belongs to rank s % nranks
 (interleaving balances sky against geometry).  The volume, palette, sky and noise are replicated.  The only
-data-path collective is ONE gather of the packed RGBA8 strips to rank 0 per step; the sharded denoiser adds
+data-path collective is ONE per step over the packed RGBA8 strips -- a gather to rank 0, or one gather per frame
+block to the rank that owns the block, issued together as a single all-to-all (ShardedBatch); the sharded denoiser adds
 a ring-neighbour exchange of `halo` guide rows (strip s needs rows of strips s-1 and s+1, which live on
 ranks r-1 and r+1).
 
@@ -206,103 +207,178 @@ class ShardedFrame:
 
 class ShardedBatch:
     """Per-rank driver for a batch of F frames (consecutive camera poses): ONE K1 launch per 8 frames over this rank's strips
-    of all of them (vrt_render_geometry_batch), one strip-pack launch, ONE gather of the whole batch to rank 0, one unpack
-    launch per 64 (frame, source) pairs there.  Geometry only (the denoiser needs the halo exchange of ShardedFrame)."""
+    of all of them (vrt_render_geometry_batch), strip packing, ONE collective per step, strip unpacking at the receivers.
+    Geometry only (the denoiser needs the halo exchange of ShardedFrame).
 
-    def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False):
+    assemble_on = "root":   every frame is gathered to rank 0 (dist.gather): the single-display case.  Rank 0 receives
+                            (N-1)/N of every frame of the batch over its 7 inbound xGMI links, so the batch rate is bound by
+                            those links once N x frame rate x frame bytes exceeds them.
+    assemble_on = "owners": frame block b (frames b*F/N .. (b+1)*F/N - 1) is gathered to rank b -- N gathers with N different
+                            roots issued as one all-to-all (dist.all_to_all_single), so every GPU receives over all of its
+                            links at once and finished frames end up spread over the ranks (each process encodes / writes
+                            its own).  xGMI is point-to-point and fully connected: this is the layout that scales on it.
+                            With rotate=True (default in this mode) block b is traced with the strip assignment rotated by
+                            b (this rank plays rank (rank + b) % N): when the strips do not divide evenly (1080 rows =
+                            67.5 strips of 16 over 8 ranks: 9 or 8 each) every rank still traces the same number of rows
+                            per step."""
+
+    def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False,
+                 assemble_on: str = "root", rotate: bool = None):
         import torch
         self.stage, self.F = stage, int(n_frames)
-        self.host_staged = bool(host_staged)       # gather through host memory (gloo rehearsal of the N > 1 path on one GPU)
+        self.host_staged = bool(host_staged)       # collective through host memory (gloo rehearsal of the N > 1 path on one GPU)
         self.rank, self.nranks, self.group = int(rank), int(nranks), group
+        if assemble_on not in ("root", "owners"):
+            raise ValueError("assemble_on must be 'root' or 'owners'")
+        self.owners = assemble_on == "owners" and self.nranks > 1
+        self.rotate = bool(self.owners if rotate is None else rotate) and self.owners
         W, H = stage._settings.renderResolution()
         self.W, self.H = W, H
         self.strip_rows = strip_rows or default_strip_rows(H, nranks)
         self.shard = _capi.Shard(self.rank, self.nranks, self.strip_rows) if nranks > 1 else None
-        self.launch = stage.prepare_batch(self.F, self.shard)
-        self.gbs = self.launch._keepalive[4]
         dev = stage.engine.torch_device
         self.prow = packed_rows(H, nranks, self.strip_rows)
+        P = C.c_void_p
+        if not self.owners:
+            self.launch = stage.prepare_batch(self.F, self.shard)
+            self.gbs = self.launch._keepalive[4]
+            self._blocks = None
+        else:
+            if self.F % self.nranks:
+                raise ValueError(f"assemble_on='owners' needs the batch ({self.F} frames) to divide over the {self.nranks} ranks")
+            self.FB = self.F // self.nranks
+            self._blocks, self.gbs = [], []
+            for b in range(self.nranks):
+                sh = _capi.Shard(self.virtual_rank(self.rank, b), self.nranks, self.strip_rows)
+                ln = stage.prepare_batch(self.FB, sh)
+                self._blocks.append((ln, sh))
+                self.gbs += ln._keepalive[4]
         if nranks > 1:
             self.packed = torch.zeros((self.F, self.prow, W, 4), dtype=torch.uint8, device=dev)
-            P = C.c_void_p
             self._full_ptrs = (P * self.F)(*[g.color.data_ptr() for g in self.gbs])
             self._packed_ptrs = (P * self.F)(*[self.packed[f].data_ptr() for f in range(self.F)])
             self._root = None
-            if rank == 0:
+            if self.owners:
+                self.finals = torch.zeros((self.FB, H, W, 4), dtype=torch.uint8, device=dev)
+            elif rank == 0:
                 self.finals = torch.zeros((self.F, H, W, 4), dtype=torch.uint8, device=dev)
+
+    def virtual_rank(self, rank: int, block: int) -> int:
+        """The strip assignment `rank` traces frame block `block` with."""
+        return (rank + block) % self.nranks if self.rotate else rank
+
+    def owned_frames(self) -> range:
+        """Batch indices of the frames that end up in self.finals on this rank."""
+        if self.nranks <= 1 or not self.owners:
+            return range(self.F) if self.rank == 0 else range(0)
+        return range(self.rank * self.FB, (self.rank + 1) * self.FB)
 
     def render(self, pushes):
         """This rank's strips of every frame; returns the GeometryBuffers (own rows valid)."""
-        return self.launch(pushes)
+        if self._blocks is None:
+            return self.launch(pushes)
+        for b, (ln, _) in enumerate(self._blocks):
+            ln(pushes[b * self.FB:(b + 1) * self.FB])
+        return self.gbs
 
     def pack(self):
-        _capi.check(_capi.lib().vrt_pack_rows_batch(self.stage.engine.ctx, self.F, self._full_ptrs, self._packed_ptrs, self.W, self.H, 4,
-                                                    C.byref(self.shard)))
+        lib, ctx = _capi.lib(), self.stage.engine.ctx
+        if self._blocks is None:
+            _capi.check(lib.vrt_pack_rows_batch(ctx, self.F, self._full_ptrs, self._packed_ptrs, self.W, self.H, 4, C.byref(self.shard)))
+            return self.packed
+        P = C.c_void_p
+        if getattr(self, "_pack_tabs", None) is None:      # per block: its slice of the pointer tables
+            self._pack_tabs = [((P * self.FB)(*self._full_ptrs[b * self.FB:(b + 1) * self.FB]),
+                                (P * self.FB)(*self._packed_ptrs[b * self.FB:(b + 1) * self.FB])) for b in range(self.nranks)]
+        for (full, packed), (_, sh) in zip(self._pack_tabs, self._blocks):
+            _capi.check(lib.vrt_pack_rows_batch(ctx, self.FB, full, packed, self.W, self.H, 4, C.byref(sh)))
         return self.packed
 
     def recv_buffers(self):
-        """Rank 0: the per-source receive buffers of the gather ([F, packed rows, W, 4] each) and, built once, the pointer
-        tables of the (frame, source) unpack."""
+        """The receive side, built once.  "root" (rank 0): one [F, packed rows, W, 4] buffer per source and the pointer
+        tables of the (source, frame) unpack.  "owners" (every rank): one buffer of the same shape as self.packed, laid out
+        [source][frame of my block], and the tables of its unpack into self.finals."""
         import torch
         if self._root is None:
-            bufs = [torch.empty_like(self.packed) for _ in range(self.nranks)]
             P = C.c_void_p
-            n = self.F * self.nranks
-            src = (P * n)(*[bufs[s][f].data_ptr() for s in range(self.nranks) for f in range(self.F)])
-            dst = (P * n)(*[self.finals[f].data_ptr() for s in range(self.nranks) for f in range(self.F)])
-            shards = (_capi.Shard * n)(*[_capi.Shard(s, self.nranks, self.strip_rows) for s in range(self.nranks) for f in range(self.F)])
-            self._root = (bufs, n, src, dst, shards)
+            if self.owners:
+                buf = torch.empty_like(self.packed)
+                n = self.F
+                src = (P * n)(*[buf[s * self.FB + j].data_ptr() for s in range(self.nranks) for j in range(self.FB)])
+                dst = (P * n)(*[self.finals[j].data_ptr() for s in range(self.nranks) for j in range(self.FB)])
+                shards = (_capi.Shard * n)(*[_capi.Shard(self.virtual_rank(s, self.rank), self.nranks, self.strip_rows)
+                                             for s in range(self.nranks) for j in range(self.FB)])
+                self._root = (buf, n, src, dst, shards)
+            else:
+                bufs = [torch.empty_like(self.packed) for _ in range(self.nranks)]
+                n = self.F * self.nranks
+                src = (P * n)(*[bufs[s][f].data_ptr() for s in range(self.nranks) for f in range(self.F)])
+                dst = (P * n)(*[self.finals[f].data_ptr() for s in range(self.nranks) for f in range(self.F)])
+                shards = (_capi.Shard * n)(*[_capi.Shard(s, self.nranks, self.strip_rows) for s in range(self.nranks) for f in range(self.F)])
+                self._root = (bufs, n, src, dst, shards)
         return self._root[0]
 
     def assemble(self):
-        """Rank 0, after the gather filled recv_buffers(): every frame of the batch into self.finals (one launch per 64
-        (frame, source) pairs)."""
+        """After the collective filled recv_buffers(): the received strips into self.finals (one launch per 64 (source, frame)
+        pairs).  Rank 0 in "root" mode, every rank in "owners" mode."""
         _, n, src, dst, shards = self._root
         _capi.check(_capi.lib().vrt_unpack_rows_batch(self.stage.engine.ctx, n, src, dst, self.W, self.H, 4, shards))
         return self.finals
 
-    def gather(self):
-        """One RCCL gather of all frames' packed strips; on rank 0 the frames are assembled into self.finals."""
-        import torch.distributed as dist
-        if self.rank != 0:
-            dist.gather(self.packed, gather_list=None, dst=0, group=self.group)
-            return None
-        dist.gather(self.packed, gather_list=self.recv_buffers(), dst=0, group=self.group)
-        return self.assemble()
+    def _receives(self) -> bool:
+        return self.owners or self.rank == 0
 
-    # -- the gather of step k overlapped with the tracing of step k + 1 -----------------------------------------------
-    def start_gather(self):
-        """Enqueue the gather without making the launch stream wait for it (async_op: the collective runs on RCCL's own
-        stream, ordered after the pack by an event)."""
+    def _collective(self, send, recv, async_op):
         import torch.distributed as dist
-        bufs = self.recv_buffers() if self.rank == 0 else None
-        if getattr(self, "host_staged", False):                  # rehearsal: device -> host, host gather, host -> device
+        if self.owners:
+            return dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        return dist.gather(send, gather_list=recv, dst=0, group=self.group, async_op=async_op)
+
+    def gather(self):
+        """One RCCL collective over all frames' packed strips (gather to rank 0, or the all-to-all of "owners"); the
+        receivers assemble their frames into self.finals."""
+        bufs = self.recv_buffers() if self._receives() else None
+        self._collective(self.packed, bufs, False)
+        return self.assemble() if self._receives() else None
+
+    # -- the collective of step k overlapped with the tracing of step k + 1 -------------------------------------------
+    def start_gather(self):
+        """Enqueue the collective without making the launch stream wait for it (async_op: it runs on RCCL's own stream,
+        ordered after the pack by an event)."""
+        bufs = self.recv_buffers() if self._receives() else None
+        if getattr(self, "host_staged", False):                  # rehearsal: device -> host, host collective, host -> device
             src = self.packed.cpu()
-            hb = [src.new_empty(src.shape) for _ in range(self.nranks)] if self.rank == 0 else None
-            self._work = dist.gather(src, gather_list=hb, dst=0, group=self.group, async_op=True)
+            if self.owners:
+                hb = src.new_empty(src.shape)
+            else:
+                hb = [src.new_empty(src.shape) for _ in range(self.nranks)] if self.rank == 0 else None
+            self._work = self._collective(src, hb, True)
             self._host = (src, hb, bufs)
             return
-        self._work = dist.gather(self.packed, gather_list=bufs, dst=0, group=self.group, async_op=True)
+        self._work = self._collective(self.packed, bufs, True)
 
     def finish(self):
-        """Make the launch stream wait for the gather in flight (if any) and, on rank 0, assemble its frames.  Returns
-        self.finals on rank 0 when a gather was completed, else None."""
+        """Make the launch stream wait for the collective in flight (if any) and assemble its frames on the receivers.
+        Returns self.finals there when a collective was completed, else None."""
         w = getattr(self, "_work", None)
         if w is None:
             return None
         w.wait()
         self._work = None
-        if getattr(self, "host_staged", False) and self.rank == 0:
+        if getattr(self, "host_staged", False) and self._receives():
             _, hb, bufs = self._host
-            for b, h in zip(bufs, hb):
-                b.copy_(h)
-        return self.assemble() if self.rank == 0 else None
+            if self.owners:
+                bufs.copy_(hb)
+            else:
+                for b, h in zip(bufs, hb):
+                    b.copy_(h)
+        return self.assemble() if self._receives() else None
 
     def step(self, pushes, overlap: bool = True):
-        """One step.  overlap=True: this step's K1 is launched first and runs while the previous step's gather is still in
-        flight; then that gather is completed (rank 0 assembles ITS frames), this step's strips are packed and their
-        gather is started.  The caller ends a sequence with finish().  Returns the frames completed by this call on rank 0
-        (the previous step's with overlap, this step's without; None elsewhere / on the first overlapped step);
+        """One step.  overlap=True: this step's K1 is launched first and runs while the previous step's collective is still
+        in flight; then that one is completed (the receivers assemble ITS frames), this step's strips are packed and their
+        collective is started.  The caller ends a sequence with finish().  Returns the frames completed by this call on a
+        receiver (the previous step's with overlap, this step's without; None elsewhere / on the first overlapped step);
         N = 1: this step's GeometryBuffers."""
         gbs = self.render(pushes)
         if self.nranks <= 1:
