@@ -187,3 +187,27 @@ def test_sharded_batch_owner_blocks_need_an_even_batch(vrt, engine):
     st = vrt.VoxelRenderSettings.primary_only((64, 48))
     with pytest.raises(ValueError):
         vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), 5, 0, 3, assemble_on="owners")
+
+
+def test_collectives_of_sharded_batch_run_on_rccl(vrt, engine):
+    """The two collectives ShardedBatch issues, on a real RCCL group (world size 1: what one GPU allows): RGBA8 strips as a
+    4-D uint8 device tensor, async_op, completion by work.wait() on the launch stream."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        D = vrt.distributed
+        sb = D.ShardedBatch.__new__(D.ShardedBatch)
+        sb.rank, sb.nranks, sb.group = 0, 1, None
+        send = torch.randint(0, 256, (8, 144, 96, 4), dtype=torch.uint8, device="cuda")
+        for owners in (True, False):
+            sb.owners = owners
+            recv = torch.zeros_like(send)
+            w = sb._collective(send, recv if owners else [recv], True)
+            w.wait()
+            torch.cuda.synchronize()
+            assert (recv == send).all(), owners
+    finally:
+        dist.destroy_process_group()
