@@ -7,8 +7,8 @@ algorithmic GB/s of the primary-ray DDA kernel against the MI355X HBM peak.
 
 A "step" is one pass of the hot path over one batch of synthetic input: a batch of N x F frames (N = number of GPUs,
 F = --frames-per-gpu, default 8; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips
-that are dealt round-robin to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch per
-8 frames (vrt_render_geometry_batch: the next frame's tiles are dispatched while the previous frame drains), packs
+that are dealt round-robin to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch
+(vrt_render_geometry_batch / _slots: the next frame's tiles are dispatched while the previous frame drains), packs
 them, and ONE RCCL collective per step moves the strips to where the frames are assembled: frame block b (F frames) is
 gathered to rank b, the N gathers issued as a single all-to-all so that every GPU receives over all of its xGMI links
 (VRT_ASSEMBLE=root: everything to rank 0 with one dist.gather instead -- bound by rank 0's inbound links).  The strip
@@ -88,16 +88,17 @@ def main():
     renderer = vrt.VoxelRenderer(engine, st, scene)
     pos0, yaw, pitch = vrt.synthetic.default_camera_for(NV, NV, NV)
     F = world * max(1, args.frames_per_gpu)                   # frames of a batch
-    poses = [np.array([pos0[0] + 1.5 * f, pos0[1] + 0.5 * f, pos0[2] + 2.0 * f], np.float32) for f in range(F)]
+    # the same dolly move at every N (8 units of travel per step), sampled world times as finely: the rays per frame and
+    # their cost do not drift with N
+    poses = [np.array([pos0[0] + 1.5 * t, pos0[1] + 0.5 * t, pos0[2] + 2.0 * t], np.float32) for t in (f / world for f in range(F))]
     pushes = []
     for f in range(F):                                        # camera + push constants per pose, marshalled once
         renderer.camera.position = poses[f]
         pushes.append(renderer.push_constants())
     assemble_on = os.environ.get("VRT_ASSEMBLE", "owners")     # where finished frames end up: "owners" | "root"
     sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world, host_staged=(backend != "nccl"),
-                                      assemble_on=assemble_on)
-    fpg = F // world
-    launches_per_step = world * ((fpg + 7) // 8) if sb.owners else (F + 7) // 8    # K1 launches per rank and step
+                                      assemble_on=assemble_on, direct="only")
+    launches_per_step = (F + 255) // 256                      # K1 launches per rank and step (VRT_MAX_TABLE frames each)
 
     overlap = os.environ.get("VRT_SYNC_GATHER", "0") != "1"
 
@@ -162,7 +163,8 @@ def main():
         st_dbg = vrt.VoxelRenderSettings.primary_only((W, H), vrt.TRAVERSAL_BITMASK)
         stage = vrt.GeometryStage(engine, st_dbg, scene, debug_planes=True)
         S_frames, hit_frac = [], []
-        for f in range(min(F, 8)):                            # the frames of the first launch of a step
+        frames_per_launch = min(F, 256)
+        for f in range(frames_per_launch):                    # the frames of the first launch of a step
             gb = stage.record(pushes[f])
             engine.synchronize()
             S_frames.append(int(gb.steps_primary.to(torch.int64).sum().item()))
@@ -170,7 +172,6 @@ def main():
             if f == 0:
                 hit0 = gb.hit_id.cpu().numpy()
         S_frame = S_frames[0]
-        frames_per_launch = min(F, 8)
         # a launch covers this rank's strips (1 / world of the rows) of frames_per_launch frames
         b_alg = (sum(S_frames) + frames_per_launch * W * H * B_OUT) / world
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
@@ -218,8 +219,8 @@ def main():
                "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"synthetic:treehouse(seed=2) {NV}^3 stand-in for treehouse.vox, {W}x{H}, primary rays only "
-                                      f"(BASELINE configs[1]); {F} frame(s)/step ({F // world} per GPU, consecutive poses, one K1 launch per 8), "
-                                      f"16-row strips round-robin over {world} GPU(s)"
+                                      f"(BASELINE configs[1]); {F} frame(s)/step ({F // world} per GPU, consecutive poses, one K1 launch per step), "
+                                      f"{sb.strip_rows}-row strips round-robin over {world} GPU(s)"
                                       + ((", one RCCL all-to-all/step (frame block b assembled on rank b), strip assignment rotated per block"
                                           if sb.owners else ", one RCCL gather/step to rank 0") if world > 1 else ""),
                           "traversal": args.traversal, "frames_per_step": F, "assembled_frames_match_single_gpu": assembled_ok, "hit_fraction": round(hit_frac[0], 4), "bytes_out_per_px": B_OUT,

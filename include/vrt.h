@@ -108,6 +108,10 @@ typedef struct vrt_frame {
     uint32_t* steps_primary; /* DDA iterations that sampled a voxel (frag:157), primary ray  */
     uint32_t* steps_total;   /* ... all rays of the pixel                   */
     uint32_t* rays_total;    /* rays traced for the pixel                   */
+    /* multi-GPU (no reference analogue): the colour once more, in the layout vrt_pack_rows produces -- the rows this rank
+     * owns, packed in increasing row order, vrt_shard_rows() rows in all (padding rows are not written).  Lets the
+     * tracing kernel fill the send buffer of the collective itself instead of a copy kernel after it. */
+    uint8_t*  color8_strips;
 } vrt_frame;
 
 /* Screen-tile sharding (no reference analogue; BASELINE north_star).  The frame is cut into
@@ -191,11 +195,19 @@ int  vrt_render_geometry(vrt_ctx* ctx, const vrt_scene* sc, const vrt_push* push
 
 /* The same for n frames of one scene, one screen size and one set of settings -- consecutive camera poses of an
  * animation (App::run's frame loop, source/app.cpp:18-27, rendered offline), or the frames of a multi-GPU batch --
- * in ONE launch per 8 frames: the tiles of frame f+1 are dispatched while frame f drains, so the tail of a frame
+ * in ONE launch (per 256 frames): the tiles of frame f+1 are dispatched while frame f drains, so the tail of a frame
  * (tens of microseconds during which most of the GPU idles) is paid once per launch instead of once per frame.
- * pushes[n], frames[n]; every frame needs its own output planes.  Results are identical to n single calls. */
+ * Up to 8 frames travel in the kernel arguments; larger batches go through a small table in device memory that is
+ * uploaded on a stream of its own.  pushes[n], frames[n]; every frame needs its own output planes.  Results are
+ * identical to n single calls. */
 int  vrt_render_geometry_batch(vrt_ctx* ctx, const vrt_scene* sc, int32_t n, const vrt_push* pushes,
                                const vrt_settings* settings, const vrt_frame* frames, const vrt_shard* shard);
+
+/* The same with one strip assignment PER FRAME (shards[n]; all with the same nranks and strip_rows): a rank of a
+ * multi-GPU batch traces frame block b with the assignment of rank (rank + b) % nranks, so that rows which do not divide
+ * evenly over the ranks still cost every rank the same per step -- in one launch.  No reference analogue. */
+int  vrt_render_geometry_slots(vrt_ctx* ctx, const vrt_scene* sc, int32_t n, const vrt_push* pushes,
+                               const vrt_settings* settings, const vrt_frame* frames, const vrt_shard* shards);
 
 /* ---- denoiser stage -------------------------------------------------------------------------- */
 #define VRT_DENOISE_CANONICAL  0  /* the intended 9-tap a-trous filter                               */

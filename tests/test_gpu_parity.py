@@ -289,7 +289,8 @@ def test_host_pointers_are_refused(vrt, engine):
 
 @pytest.mark.parametrize("mode", ["primary_only", "default", "split"])
 def test_batch_of_frames_equals_single_calls(vrt, oracle, engine, mode):
-    """vrt_render_geometry_batch: 11 poses (two launches: 8 + 3) must give exactly the planes of 11 single calls; three of
+    """vrt_render_geometry_batch: 11 poses (one launch, slots read from the table in device memory; one launch per frame in
+    split mode) must give exactly the planes of 11 single calls; three of
     them are also checked against the oracle.  Sharded: the strips of a simulated rank only."""
     vol = vrt.synthetic.treehouse(64, seed=4)
     pal = metallic_palette(vrt)
@@ -317,6 +318,45 @@ def test_batch_of_frames_equals_single_calls(vrt, oracle, engine, mode):
                 exp = oracle.render(osn, pushes[f], oracle.params_from(st.to_c()), nthreads=8)
                 assert not compare_planes(batch[f], exp, names), f
     assert any((b["hit_id"] != batch[0]["hit_id"]).any() for b in batch[1:])           # the poses really differ
+
+
+@pytest.mark.parametrize("n", [5, 19])
+def test_frames_with_their_own_strip_assignment_equal_single_calls(vrt, engine, n):
+    """vrt_render_geometry_slots: every frame of the launch plays another rank of a 3-rank split of 136 rows (8.5 strips:
+    the ranks own 48, 48 and 40 rows); 5 frames travel in the kernel arguments, 19 in the device table.  The launch is
+    repeated more often than the table ring is long, with the poses in another order each time."""
+    vol = vrt.synthetic.treehouse(64, seed=4)
+    gs = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt), sky=vrt.synthetic.sky_gradient(64, 32), noise=vrt.synthetic.blue_noise_standin(64))
+    res = (200, 136)
+    st = vrt.VoxelRenderSettings(targetResolution=res)
+    st.fsrSetttings.enable = False
+    st.traceSettings.maxReflections = 1
+    pushes = [camera_push(vrt, (64, 64, 64), res, frame=f, pos=(30.0 + 1.5 * f, 31.0 + 0.5 * f, -50.0 + 3.0 * f), yaw=90.0 - 2.0 * f)
+              for f in range(n)]
+    ranks = [(2 * f + 1) % 3 for f in range(n)]
+    stage = vrt.GeometryStage(engine, st, gs)
+    launch = stage.prepare_batch(n, shards=[vrt.make_shard(r, 3, 16) for r in ranks])
+    names = GB
+    singles = {}
+    for rep in range(6):
+        order = [(f + rep) % n for f in range(n)]               # slot k renders pose order[k] with the assignment of slot k
+        batch = [g.numpy() for g in launch([pushes[f] for f in order])]
+        engine.synchronize()
+        if rep not in (0, 5):
+            continue
+        for k, f in enumerate(order):
+            if (f, ranks[k]) not in singles:
+                singles[(f, ranks[k])] = stage.record(pushes[f], vrt.make_shard(ranks[k], 3, 16)).numpy()
+                engine.synchronize()
+            sn = singles[(f, ranks[k])]
+            own = ((np.arange(res[1]) // 16) % 3) == ranks[k]
+            bad = compare_planes({m: batch[k][m][own] for m in names}, {m: sn[m][own] for m in names}, names)
+            assert not bad, (rep, k, f, bad)
+    with pytest.raises(ValueError):
+        stage.prepare_batch(n, shards=[vrt.make_shard(0, 3, 16)] * (n - 1))
+    bad_mix = [vrt.make_shard(0, 3, 16)] * (n - 1) + [vrt.make_shard(0, 2, 16)]
+    with pytest.raises(vrt.VrtError):
+        stage.prepare_batch(n, shards=bad_mix)(pushes)
 
 
 def test_two_contexts_share_a_scene(vrt, oracle, engine):

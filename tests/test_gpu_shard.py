@@ -211,3 +211,41 @@ def test_collectives_of_sharded_batch_run_on_rccl(vrt, engine):
             assert (recv == send).all(), owners
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["primary_only", "megakernel", "split"])
+def test_color8_strips_is_the_packed_colour(vrt, engine, mode):
+    """vrt_frame.color8_strips: the tracing kernel's own copy of the colour in packed-strip order must be what
+    vrt_pack_rows makes of the full colour plane -- for every rank of an uneven split (136 rows, 3 ranks) and unsharded."""
+    vol = vrt.synthetic.treehouse(48, seed=6)
+    sc = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt), sky=vrt.synthetic.sky_gradient(64, 32), noise=vrt.synthetic.blue_noise_standin(64))
+    res = (208, 136)
+    W, H = res
+    st = vrt.VoxelRenderSettings.primary_only(res) if mode == "primary_only" else vrt.VoxelRenderSettings(targetResolution=res)
+    st.fsrSetttings.enable = False
+    st.traceSettings.splitKernels = mode == "split"
+    stage = vrt.GeometryStage(engine, st, sc)
+    L = vrt._capi.lib()
+    n = 3
+    pushes = [vrt.make_push(vrt.CameraController(position=(24.0 + f, 25.0, -40.0 + 2.0 * f)), (48, 48, 48), res) for f in range(n)]
+    for shard in (None, vrt.make_shard(0, 3, 16), vrt.make_shard(2, 3, 16)):
+        prow = vrt.distributed.packed_rows(H, 3, 16) if shard is not None else H
+        launch = stage.prepare_batch(n, shard)
+        strips = torch.full((n, prow, W, 4), 77, dtype=torch.uint8, device="cuda")
+        tab = (vrt._capi.Frame * n)()
+        C.memmove(tab, launch._keepalive[1], C.sizeof(tab))
+        for f in range(n):
+            tab[f].color8_strips = strips[f].data_ptr()
+        gbs = launch(pushes, tab)
+        engine.synchronize()
+        for f in range(n):
+            want = torch.full((prow, W, 4), 77, dtype=torch.uint8, device="cuda")
+            if shard is None:
+                want.copy_(gbs[f].color)
+            else:
+                assert L.vrt_pack_rows(engine.ctx, gbs[f].color.data_ptr(), want.data_ptr(), W, H, 4, C.byref(shard)) == 0
+                engine.synchronize()
+                rm = vrt.distributed.packed_row_map(H, shard.rank, 3, 16)
+                want[torch.from_numpy(rm < 0).cuda()] = 77                       # padding rows: untouched by the kernel
+            assert (strips[f] == want).all(), (mode, shard is not None and shard.rank, f)
+        assert strips.ne(77).any()

@@ -39,7 +39,7 @@ class Settings(C.Structure):
 
 
 FRAME_PLANES = ["color8", "depth", "motion", "mask8", "position", "normal8", "color_f", "hit_id",
-                "hit_voxel", "hit_mask", "steps_primary", "steps_total", "rays_total"]
+                "hit_voxel", "hit_mask", "steps_primary", "steps_total", "rays_total", "color8_strips"]
 
 
 class Frame(C.Structure):
@@ -91,6 +91,7 @@ SYMBOLS = {
     "vrt_settings_default": (None, [C.POINTER(Settings)]),
     "vrt_render_geometry": (C.c_int, [_P, _P, C.POINTER(Push), C.POINTER(Settings), C.POINTER(Frame), C.POINTER(Shard)]),
     "vrt_render_geometry_batch": (C.c_int, [_P, _P, C.c_int32, C.POINTER(Push), C.POINTER(Settings), C.POINTER(Frame), C.POINTER(Shard)]),
+    "vrt_render_geometry_slots": (C.c_int, [_P, _P, C.c_int32, C.POINTER(Push), C.POINTER(Settings), C.POINTER(Frame), C.POINTER(Shard)]),
     "vrt_denoiser_settings_default": (None, [C.POINTER(DenoiserSettings)]),
     "vrt_denoise": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(DenoiserSettings), _P, _P, _P, _P, _P,
                               C.POINTER(Shard), C.POINTER(_P)]),

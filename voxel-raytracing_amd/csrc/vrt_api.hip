@@ -46,6 +46,16 @@ struct vrt_ctx {
     uint32_t* hit_list = nullptr;     // [records_px] + 1 counter word at the end
     size_t records_px = 0;
     uint64_t checked_ptrs[2] = {0, 0};   // digests of the image pointers last verified to be device memory (geometry, denoiser)
+    // frame-slot tables of launches with more than VRT_MAX_BATCH frames: a ring of device tables, each with a pinned host
+    // image that is uploaded on a stream of its own (the copy runs while the previous launch is still tracing)
+    static constexpr int kTabRing = 4;
+    FrameSlot* tab_dev[kTabRing] = {nullptr, nullptr, nullptr, nullptr};
+    FrameSlot* tab_host[kTabRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t tab_uploaded[kTabRing] = {nullptr, nullptr, nullptr, nullptr};   // on upload_stream: table i is in device memory
+    hipEvent_t tab_consumed[kTabRing] = {nullptr, nullptr, nullptr, nullptr};   // on stream: the launch that read table i is done
+    bool tab_busy[kTabRing] = {false, false, false, false};
+    int tab_next = 0;
+    hipStream_t upload_stream = nullptr;
 };
 
 struct vrt_scene {
@@ -89,6 +99,13 @@ void vrt_ctx_destroy(vrt_ctx* c)
     hipStreamSynchronize(c->stream);
     if (c->records) hipFree(c->records);
     if (c->hit_list) hipFree(c->hit_list);
+    if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
+    for (int i = 0; i < vrt_ctx::kTabRing; i++) {
+        if (c->tab_dev[i]) hipFree(c->tab_dev[i]);
+        if (c->tab_host[i]) hipHostFree(c->tab_host[i]);
+        if (c->tab_uploaded[i]) hipEventDestroy(c->tab_uploaded[i]);
+        if (c->tab_consumed[i]) hipEventDestroy(c->tab_consumed[i]);
+    }
     hipEventDestroy(c->ev_geo0); hipEventDestroy(c->ev_prim1); hipEventDestroy(c->ev_geo1);
     hipEventDestroy(c->ev_den0); hipEventDestroy(c->ev_den1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -483,9 +500,28 @@ int vrt_shard_rows(int32_t H, const vrt_shard* sh)
 
 // ---- geometry stage --------------------------------------------------------------------------------
 
-// One launch of K1 over n <= VRT_MAX_BATCH frames (K2 follows per frame in split mode, which renders one frame at a time).
+// The next table of the ring, ready to be filled on the host (its previous launch, kTabRing launches ago, has finished).
+static int next_table(vrt_ctx* c, int* idx)
+{
+    const int i = c->tab_next;
+    c->tab_next = (c->tab_next + 1) % vrt_ctx::kTabRing;
+    if (!c->upload_stream) HIPCHK(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+    if (!c->tab_dev[i]) {
+        HIPCHK(hipMalloc((void**)&c->tab_dev[i], sizeof(FrameSlot) * VRT_MAX_TABLE));
+        HIPCHK(hipHostMalloc((void**)&c->tab_host[i], sizeof(FrameSlot) * VRT_MAX_TABLE, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->tab_uploaded[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->tab_consumed[i], hipEventDisableTiming));
+    }
+    if (c->tab_busy[i]) { HIPCHK(hipEventSynchronize(c->tab_consumed[i])); c->tab_busy[i] = false; }
+    *idx = i;
+    return VRT_OK;
+}
+
+// One launch of K1 over n frames: n <= VRT_MAX_BATCH slots travel in the kernel arguments, more (<= VRT_MAX_TABLE) in a
+// table in device memory.  shards: one strip assignment for all frames (per_frame == 0) or one per frame, all with the
+// same nranks and strip_rows.  K2 follows in split mode, which renders one frame at a time.
 static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* pushes, const vrt_settings* st,
-                         const vrt_frame* frames, const vrt_shard* shard)
+                         const vrt_frame* frames, const vrt_shard* shards, int per_frame)
 {
     const vrt_push* push = &pushes[0];
     int W = push->screen_size[0], H = push->screen_size[1];
@@ -503,14 +539,15 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: VRT_TRAVERSAL_DENSE indexes voxels in 32 bits (volumes below 4 GiB)");
     HIPCHK(hipSetDevice(c->device));
     {
-        const void* ptrs[13 * VRT_MAX_BATCH];
+        std::vector<const void*> ptrs((size_t)14 * (size_t)n);
         for (int f = 0; f < n; f++) {
             const vrt_frame* frame = &frames[f];
-            const void* one[13] = {frame->color8, frame->depth, frame->motion, frame->mask8, frame->position, frame->normal8, frame->color_f,
-                                   frame->hit_id, frame->hit_voxel, frame->hit_mask, frame->steps_primary, frame->steps_total, frame->rays_total};
-            memcpy(&ptrs[13 * f], one, sizeof one);
+            const void* one[14] = {frame->color8, frame->depth, frame->motion, frame->mask8, frame->position, frame->normal8, frame->color_f,
+                                   frame->hit_id, frame->hit_voxel, frame->hit_mask, frame->steps_primary, frame->steps_total, frame->rays_total,
+                                   frame->color8_strips};
+            memcpy(&ptrs[(size_t)14 * f], one, sizeof one);
         }
-        int prc = check_device_ptrs(c, 0, ptrs, 13 * n, "vrt_render_geometry");
+        int prc = check_device_ptrs(c, 0, ptrs.data(), 14 * n, "vrt_render_geometry");
         if (prc != VRT_OK) return prc;
     }
 
@@ -518,9 +555,33 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     memset(&p, 0, sizeof p);
     p.sc = s->d; p.st = *st;
     p.n_frames = n; p.W = W; p.H = H;
-    for (int f = 0; f < n; f++) { p.slot[f].pc = pushes[f]; p.slot[f].fr = frames[f]; p.slot[f].rg = raygen_consts(pushes[f]); }
-    int rc = make_shard(shard, H, p.sh, nullptr);
+    int max_strips = 1;
+    int rc = make_shard(shards, H, p.sh, &max_strips);
     if (rc != VRT_OK) return rc;
+    int local_strips = p.sh.n_local_strips;
+    if (per_frame && shards) {
+        for (int f = 1; f < n; f++) {
+            ShardMap m;
+            rc = make_shard(&shards[f], H, m, nullptr);
+            if (rc != VRT_OK) return rc;
+            if (m.nranks != p.sh.nranks || m.strip_rows != p.sh.strip_rows)
+                return fail(VRT_ERR_INVALID, "vrt_render_geometry_slots: the frames of a launch must share nranks and strip_rows");
+        }
+        local_strips = p.sh.nranks > 1 ? max_strips : p.sh.n_local_strips;    // the grid covers the longest assignment
+    }
+    FrameSlot* slots = p.slot;
+    int tab = -1;
+    if (n > VRT_MAX_BATCH) {
+        rc = next_table(c, &tab);
+        if (rc != VRT_OK) return rc;
+        slots = c->tab_host[tab];
+        p.table = c->tab_dev[tab];
+    }
+    for (int f = 0; f < n; f++) {
+        slots[f].pc = pushes[f]; slots[f].fr = frames[f]; slots[f].rg = raygen_consts(pushes[f]);
+        slots[f].shard_rank = (per_frame && shards) ? shards[f].rank : p.sh.rank;
+        slots[f].pad = 0;
+    }
     // LDS-staged traversals amortise the staging over a 16x16 tile (4 waves); the others run one 8x8 wave per workgroup,
     // which frees a wave slot the moment a wave finishes instead of when its whole tile does
     {
@@ -529,13 +590,15 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         p.tile_w = p.tile_h = (lds_mode || (st->flags & 8u)) ? 16 : 8;
     }
     p.tiles_x = ceil_div(W, p.tile_w);
-    p.tiles_y_local = p.sh.n_local_strips * (p.sh.strip_rows / p.tile_h);
+    p.tiles_y_local = local_strips * (p.sh.strip_rows / p.tile_h);
     p.total_tiles = p.tiles_x * p.tiles_y_local;
     p.chunk = p.tiles_x * ceil_div(p.tiles_y_local, 8);      // workgroups per XCD slot (tile rows are dealt round-robin)
     p.wgs_per_frame = (uint32_t)p.chunk * 8u;
+    p.xcd_turn = (n > 1 && p.tiles_y_local > 0 && ceil_div(p.tiles_y_local, 8) * 8 * 100 > p.tiles_y_local * 103) ? 1 : 0;
     p.wgs_per_frame_rcp = p.wgs_per_frame ? (uint32_t)(0x100000000ull / (uint64_t)p.wgs_per_frame) : 0u;
     p.tps = (uint32_t)(p.sh.strip_rows / p.tile_h);
     p.tiles_x_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tiles_x);
+    p.tiles_y_rcp = p.tiles_y_local ? (uint32_t)(0x100000000ull / (uint64_t)p.tiles_y_local) : 0u;
     p.tps_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tps);
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
@@ -558,11 +621,31 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         HIPCHK(hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), c->stream));
     }
     if (p.total_tiles == 0) return VRT_OK;
+    if (tab >= 0) {
+        HIPCHK(hipMemcpyAsync(c->tab_dev[tab], c->tab_host[tab], sizeof(FrameSlot) * (size_t)n, hipMemcpyHostToDevice, c->upload_stream));
+        HIPCHK(hipEventRecord(c->tab_uploaded[tab], c->upload_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->tab_uploaded[tab], 0));
+    }
     if (c->timing) HIPCHK(hipEventRecord(c->ev_geo0, c->stream));
     HIPCHK(launch_primary(p, c->stream));
+    if (tab >= 0) { HIPCHK(hipEventRecord(c->tab_consumed[tab], c->stream)); c->tab_busy[tab] = true; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev_prim1, c->stream));
     if (!p.fused_shade) HIPCHK(launch_shade(p, c->stream));
     if (c->timing) { HIPCHK(hipEventRecord(c->ev_geo1, c->stream)); c->have_geo = true; }
+    return VRT_OK;
+}
+
+static int render_many(vrt_ctx* c, const vrt_scene* s, int32_t n, const vrt_push* pushes, const vrt_settings* st,
+                       const vrt_frame* frames, const vrt_shard* shards, int per_frame)
+{
+    // the split form keeps one frame's hit records: one frame per launch there
+    const bool split = (st->flags & VRT_FLAG_SPLIT_KERNELS) && !(st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0);
+    const int per_launch = split ? 1 : VRT_MAX_TABLE;
+    for (int f0 = 0; f0 < n; f0 += per_launch) {
+        int m = n - f0 < per_launch ? n - f0 : per_launch;
+        int rc = render_frames(c, s, m, pushes + f0, st, frames + f0, (per_frame && shards) ? shards + f0 : shards, per_frame);
+        if (rc != VRT_OK) return rc;
+    }
     return VRT_OK;
 }
 
@@ -570,7 +653,7 @@ int vrt_render_geometry(vrt_ctx* c, const vrt_scene* s, const vrt_push* push, co
                         const vrt_frame* frame, const vrt_shard* shard)
 {
     if (!c || !s || !push || !st || !frame) return fail(VRT_ERR_INVALID, "vrt_render_geometry: NULL argument");
-    return render_frames(c, s, 1, push, st, frame, shard);
+    return render_frames(c, s, 1, push, st, frame, shard, 0);
 }
 
 int vrt_render_geometry_batch(vrt_ctx* c, const vrt_scene* s, int32_t n, const vrt_push* pushes, const vrt_settings* st,
@@ -578,14 +661,15 @@ int vrt_render_geometry_batch(vrt_ctx* c, const vrt_scene* s, int32_t n, const v
 {
     if (!c || !s || !pushes || !st || !frames) return fail(VRT_ERR_INVALID, "vrt_render_geometry_batch: NULL argument");
     if (n < 0) return fail(VRT_ERR_INVALID, "vrt_render_geometry_batch: n < 0");
-    // the split form keeps one frame's hit records: one frame per launch there
-    const int per_launch = (st->flags & VRT_FLAG_SPLIT_KERNELS) && !(st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : VRT_MAX_BATCH;
-    for (int f0 = 0; f0 < n; f0 += per_launch) {
-        int m = n - f0 < per_launch ? n - f0 : per_launch;
-        int rc = render_frames(c, s, m, pushes + f0, st, frames + f0, shard);
-        if (rc != VRT_OK) return rc;
-    }
-    return VRT_OK;
+    return render_many(c, s, n, pushes, st, frames, shard, 0);
+}
+
+int vrt_render_geometry_slots(vrt_ctx* c, const vrt_scene* s, int32_t n, const vrt_push* pushes, const vrt_settings* st,
+                              const vrt_frame* frames, const vrt_shard* shards)
+{
+    if (!c || !s || !pushes || !st || !frames || !shards) return fail(VRT_ERR_INVALID, "vrt_render_geometry_slots: NULL argument");
+    if (n < 0) return fail(VRT_ERR_INVALID, "vrt_render_geometry_slots: n < 0");
+    return render_many(c, s, n, pushes, st, frames, shards, 1);
 }
 
 // ---- denoiser stage --------------------------------------------------------------------------------

@@ -358,25 +358,68 @@ __device__ __forceinline__ uint32_t udiv_uniform(uint32_t n, uint32_t d, uint32_
     return q;
 }
 
-__device__ __forceinline__ bool tile_origin(const GeomParams& P, int& x0, int& y0, uint32_t& frame)
+// The slot (camera, planes, strip assignment) of frame `frame` of the launch.  TABLE = false: a reference into the kernel
+// arguments.  TABLE = true (launches of more than VRT_MAX_BATCH frames): a copy read from the table in device memory
+// through the constant address space -- the table is not written while the kernel runs, and only loads the compiler
+// knows to be invariant become scalar loads (a plain global pointer gives vector loads and the slot in VGPRs).
+typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+template <bool TABLE> struct SlotOf;
+template <> struct SlotOf<false> {
+    typedef const FrameSlot& type;
+    static __device__ __forceinline__ const FrameSlot& get(const GeomParams& P, uint32_t frame) { return P.slot[frame]; }
+};
+template <> struct SlotOf<true> {
+    typedef const FrameSlot type;
+    static __device__ __forceinline__ FrameSlot get(const GeomParams& P, uint32_t frame)
+    {
+        const_u32_ptr w = (const_u32_ptr)(P.table + frame);
+        uint32_t tmp[sizeof(FrameSlot) / 4];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(FrameSlot) / 4); i++) tmp[i] = w[i];
+        FrameSlot S;
+        __builtin_memcpy(&S, tmp, sizeof S);
+        return S;
+    }
+};
+
+// workgroup -> frame of the launch and tile row within the frame's local rows (ty) and tile column (tx).  Frames of a
+// batch follow one another in the grid: the next frame's first tiles start while this one drains.
+// XCD x (= workgroup id & 7) owns every 8th tile row: every XCD gets an even sample of sky and geometry (a contiguous
+// band per XCD leaves the XCDs that drew the sky idle), while the tiles of one row -- which walk neighbouring volume cells
+// -- still share that XCD's L2.
+//   xcd_turn == 0: per frame, row ty belongs to XCD ty % 8; ceil(rows / 8) * 8 row slots per frame (the surplus
+//                  workgroups exit at once).  The same rows of consecutive poses meet in the same L2 while two frames
+//                  overlap in the machine (worth 1 %).
+//   xcd_turn == 1: the rows of ALL frames of the launch are dealt round-robin in one sequence (row L = frame * rows + ty
+//                  to XCD L % 8).  For row counts far from a multiple of 8 -- a rank's 18 rows of a sharded 1080p frame
+//                  would be 3 rows for two XCDs and 2 for the others, and a third of the grid would be surplus -- the XCDs
+//                  stay even and only the last seven row slots of the launch can be empty.
+__device__ __forceinline__ bool block_to_tile(const GeomParams& P, uint32_t& frame, int& ty, int& tx)
 {
-    // frames of a batch follow one another in the grid: the next frame's first tiles start while this one drains
-    uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x, utx;
     frame = 0;
+    if (P.xcd_turn) {
+        uint32_t L = udiv_uniform(b >> 3, (uint32_t)P.tiles_x, P.tiles_x_rcp, utx) * 8u + (b & 7u), uty;
+        frame = udiv_uniform(L, (uint32_t)P.tiles_y_local, P.tiles_y_rcp, uty);
+        ty = (int)uty; tx = (int)utx;
+        return frame < (uint32_t)P.n_frames;
+    }
     if (P.n_frames > 1) frame = udiv_uniform(blockIdx.x, P.wgs_per_frame, P.wgs_per_frame_rcp, b);
-    // XCD slot (b & 7) owns tile rows ty with ty % 8 == slot: every XCD gets an even sample of sky and
-    // geometry (a contiguous band per XCD leaves the XCDs that drew the sky idle), while the tiles of one
-    // row -- which walk neighbouring volume cells -- still share that XCD's L2.
-    uint32_t slot = b & 7u, idx = b >> 3, utx;
-    int ty = (int)(udiv_uniform(idx, (uint32_t)P.tiles_x, P.tiles_x_rcp, utx) * 8u + slot), tx = (int)utx;
-    if (ty >= P.tiles_y_local) return false;
+    ty = (int)(udiv_uniform(b >> 3, (uint32_t)P.tiles_x, P.tiles_x_rcp, utx) * 8u + (b & 7u)); tx = (int)utx;
+    return ty < P.tiles_y_local;
+}
+
+// yp0: the row of y0 in the rank's packed strips (vrt_pack_rows order)
+__device__ __forceinline__ bool tile_origin(const GeomParams& P, int ty, int tx, int shard_rank, int& x0, int& y0, int& yp0)
+{
     // bottom rows first: the rows dispatched last only have the drain of the machine to hide in, and the top of a
     // frame is where the cheap sky-only tiles usually are
     ty = P.tiles_y_local - 1 - ty;
     uint32_t within;
     int strip_local = (int)udiv_uniform((uint32_t)ty, P.tps, P.tps_rcp, within);
     x0 = tx * P.tile_w;
-    y0 = (strip_local * P.sh.nranks + P.sh.rank) * P.sh.strip_rows + (int)within * P.tile_h;
+    yp0 = strip_local * P.sh.strip_rows + (int)within * P.tile_h;
+    y0 = (strip_local * P.sh.nranks + shard_rank) * P.sh.strip_rows + (int)within * P.tile_h;
     return y0 < P.H;
 }
 
@@ -408,16 +451,16 @@ template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomPara
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
-template <int TRAV, bool OCC_LDS, int MODE>
+template <int TRAV, bool OCC_LDS, int MODE, bool TABLE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_primary(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     const uint64_t t_begin = (P.st.flags & 2u) ? wall_clock64() : 0ull;      // diagnostic timeline (100 MHz)
-    int x0, y0;
+    int x0, y0, yp0, ty, tx;
     uint32_t frame;
-    bool live = tile_origin(P, x0, y0, frame);          // uniform per workgroup
-    if (!live) return;
-    const FrameSlot& S = P.slot[frame];
+    if (!block_to_tile(P, frame, ty, tx)) return;                        // uniform per workgroup
+    typename SlotOf<TABLE>::type S = SlotOf<TABLE>::get(P, frame);
+    if (!tile_origin(P, ty, tx, S.shard_rank, x0, y0, yp0)) return;
     constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
     const OccT<kLds> occ = stage_occ<kLds>(P, lds_occ);
 
@@ -479,9 +522,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             col = sky_color(s, dir);
         }
         if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
-        if (f.color8) {
+        if (f.color8 || f.color8_strips) {
             uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
-            reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+            if (f.color8) reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+            if (f.color8_strips) reinterpret_cast<uchar4*>(f.color8_strips)[(size_t)(yp0 + (py - y0)) * (size_t)W + (size_t)px] = c8;
         }
     } else if (hit) {
         // hit record for K2 (position bits + material | mask << 8 | (step+1) codes) and a slot in the compacted list of
@@ -496,9 +540,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         // misses are final here: colorMainRay is never reached (voxel_volume.frag:337-345)
         f3 col = sky_color(s, dir);
         if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
-        if (f.color8) {
+        if (f.color8 || f.color8_strips) {
             uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
-            reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+            if (f.color8) reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+            if (f.color8_strips) reinterpret_cast<uchar4*>(f.color8_strips)[(size_t)(yp0 + (py - y0)) * (size_t)W + (size_t)px] = c8;
         }
     }
 }
@@ -533,9 +578,14 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     f3 col = color_main_ray<TRAV>(P, occ, c, h);
     const vrt_frame& f = P.slot[0].fr;
     if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
-    if (f.color8) {
+    if (f.color8 || f.color8_strips) {
         uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
-        reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+        if (f.color8) reinterpret_cast<uchar4*>(f.color8)[i] = c8;
+        if (f.color8_strips) {                 // the split form has no tile: row -> packed row by division
+            int strip = py / P.sh.strip_rows;
+            int yp = (strip / P.sh.nranks) * P.sh.strip_rows + (py - strip * P.sh.strip_rows);
+            reinterpret_cast<uchar4*>(f.color8_strips)[(size_t)yp * (size_t)P.W + (size_t)px] = c8;
+        }
     }
     if (f.steps_total) f.steps_total[i] += c.fetches;
     if (f.rays_total) f.rays_total[i] += c.rays;
@@ -548,11 +598,18 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
 template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
-    dim3 grid((unsigned)(p.chunk * 8) * (unsigned)p.n_frames), block(p.tile_h == 8 ? 64 : 256);
+    unsigned wgs = (unsigned)(p.chunk * 8) * (unsigned)p.n_frames;
+    if (p.xcd_turn) wgs = (unsigned)p.tiles_x * 8u * (unsigned)((p.tiles_y_local * p.n_frames + 7) / 8);
+    dim3 grid(wgs), block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
-    if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1>), grid, block, lds, s, p);
-    else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2>), grid, block, lds, s, p);
-    else                         hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 0>), grid, block, lds, s, p);
+    if (p.table) {               // the split form renders one frame per launch and never gets here
+        if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, true>), grid, block, lds, s, p);
+        else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, true>), grid, block, lds, s, p);
+        else return hipErrorInvalidValue;
+    }
+    else if (p.fused_shade == 1) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, false>), grid, block, lds, s, p);
+    else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, false>), grid, block, lds, s, p);
+    else                         hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 0, false>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -50,21 +50,28 @@ inline RayGenConsts raygen_consts(const vrt_push& pc)
     return g;
 }
 
-// One frame of a launch: camera (push block + its hoisted part) and output planes.
+// One frame of a launch: camera (push block + its hoisted part), output planes and the strip assignment it is traced
+// with (the rank of ShardMap; frames of one launch may play different ranks: vrt_render_geometry_slots).
 struct FrameSlot {
     RayGenConsts rg;
     vrt_push     pc;
     vrt_frame    fr;
+    int32_t      shard_rank;
+    int32_t      pad;
 };
+static_assert(sizeof(FrameSlot) == 256, "FrameSlot is sized for aligned scalar loads");
 
-#define VRT_MAX_BATCH 8      // frames per K1 launch (vrt_render_geometry_batch); 8 x 248 B of kernel arguments
+#define VRT_MAX_BATCH 8      // frames per K1 launch whose slots travel in the kernel arguments (8 x 256 B)
+#define VRT_MAX_TABLE 256    // frames per K1 launch whose slots are read from a table in device memory
 
 struct GeomParams {
     // A launch covers n_frames frames of one scene, one resolution and one set of settings (consecutive camera poses of an
     // animation, or the frames of a multi-GPU batch): workgroup b works on frame b / wgs_per_frame.  Frame f+1's tiles are
     // dispatched while frame f drains, so the ~30 us tail of a frame is paid once per launch instead of once per frame.
     FrameSlot  slot[VRT_MAX_BATCH];
+    const FrameSlot* table;    // non-null: n_frames (<= VRT_MAX_TABLE) slots in device memory instead of slot[]
     int32_t    n_frames;
+    int32_t    xcd_turn;       // 1: tile rows of all frames are dealt to the XCDs in one sequence (block_to_tile)
     uint32_t   wgs_per_frame, wgs_per_frame_rcp;   // chunk * 8 and floor(2^32 / that)
     int32_t    W, H;                               // screen size (common to the frames)
     DevScene   sc;
@@ -72,6 +79,7 @@ struct GeomParams {
     ShardMap   sh;
     int32_t    tile_w, tile_h; // workgroup tile in pixels: 16x16 (4 waves of 8x8) or 8x8 (one wave)
     int32_t    tiles_x, tiles_y_local, total_tiles, chunk;  // chunk = tiles per XCD slot
+    uint32_t   tiles_y_rcp;    // floor(2^32 / tiles_y_local), for xcd_turn
     uint32_t   tiles_x_rcp, tps, tps_rcp;  // floor(2^32 / d) for the two wave-uniform divisions of tile_origin (scalar unit);
                                        // tps = tiles per strip (strip_rows / tile_h)
     uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)

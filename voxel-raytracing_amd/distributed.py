@@ -23,6 +23,12 @@ def default_strip_rows(H: int, nranks: int) -> int:
     return 16
 
 
+def band_strip_rows(H: int, nranks: int) -> int:
+    """One strip per rank: contiguous bands of ceil(H / nranks) rows, rounded up to 16.  Only balanced when the
+    assignment rotates (ShardedBatch(rotate=True)): a band of sky costs a fraction of a band of geometry."""
+    return max(16, (((H + nranks - 1) // nranks) + 15) // 16 * 16)
+
+
 def n_strips(H: int, strip_rows: int) -> int:
     return (H + strip_rows - 1) // strip_rows
 
@@ -206,8 +212,8 @@ class ShardedFrame:
 
 
 class ShardedBatch:
-    """Per-rank driver for a batch of F frames (consecutive camera poses): ONE K1 launch per 8 frames over this rank's strips
-    of all of them (vrt_render_geometry_batch), strip packing, ONE collective per step, strip unpacking at the receivers.
+    """Per-rank driver for a batch of F frames (consecutive camera poses): ONE K1 launch over this rank's strips of all of
+    them (vrt_render_geometry_batch / _slots), strip packing, ONE collective per step, strip unpacking at the receivers.
     Geometry only (the denoiser needs the halo exchange of ShardedFrame).
 
     assemble_on = "root":   every frame is gathered to rank 0 (dist.gather): the single-display case.  Rank 0 receives
@@ -220,10 +226,16 @@ class ShardedBatch:
                             With rotate=True (default in this mode) block b is traced with the strip assignment rotated by
                             b (this rank plays rank (rank + b) % N): when the strips do not divide evenly (1080 rows =
                             67.5 strips of 16 over 8 ranks: 9 or 8 each) every rank still traces the same number of rows
-                            per step."""
+                            per step.
+    direct = True:          K1 itself writes the colour a second time in packed-strip order (vrt_frame.color8_strips) into
+                            the send buffer, so pack() has nothing left to do; the send buffer is double-buffered because
+                            the collective of step k is still reading it while step k + 1 is traced.  direct = "only":
+                            the packed copy is the only colour K1 stores (the GeometryBuffers' colour planes stay
+                            unwritten).  direct = False keeps the copy kernel (vrt_pack_rows_batch) between K1 and the
+                            collective."""
 
     def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False,
-                 assemble_on: str = "root", rotate: bool = None):
+                 assemble_on: str = "root", rotate: bool = None, direct: bool = True):
         import torch
         self.stage, self.F = stage, int(n_frames)
         self.host_staged = bool(host_staged)       # collective through host memory (gloo rehearsal of the N > 1 path on one GPU)
@@ -234,30 +246,43 @@ class ShardedBatch:
         self.rotate = bool(self.owners if rotate is None else rotate) and self.owners
         W, H = stage._settings.renderResolution()
         self.W, self.H = W, H
-        self.strip_rows = strip_rows or default_strip_rows(H, nranks)
+        # with the rotation every rank traces every part of the screen once per step, so the strips need not interleave to
+        # balance sky against geometry: one contiguous band per rank keeps a rank's rays next to each other
+        self.strip_rows = strip_rows or (band_strip_rows(H, nranks) if self.rotate else default_strip_rows(H, nranks))
         self.shard = _capi.Shard(self.rank, self.nranks, self.strip_rows) if nranks > 1 else None
         dev = stage.engine.torch_device
         self.prow = packed_rows(H, nranks, self.strip_rows)
         P = C.c_void_p
         if not self.owners:
             self.launch = stage.prepare_batch(self.F, self.shard)
-            self.gbs = self.launch._keepalive[4]
             self._blocks = None
         else:
             if self.F % self.nranks:
                 raise ValueError(f"assemble_on='owners' needs the batch ({self.F} frames) to divide over the {self.nranks} ranks")
             self.FB = self.F // self.nranks
-            self._blocks, self.gbs = [], []
-            for b in range(self.nranks):
-                sh = _capi.Shard(self.virtual_rank(self.rank, b), self.nranks, self.strip_rows)
-                ln = stage.prepare_batch(self.FB, sh)
-                self._blocks.append((ln, sh))
-                self.gbs += ln._keepalive[4]
+            # the strip assignment of every block; ONE launch traces all blocks (vrt_render_geometry_slots)
+            self._blocks = [_capi.Shard(self.virtual_rank(self.rank, b), self.nranks, self.strip_rows) for b in range(self.nranks)]
+            self.launch = stage.prepare_batch(self.F, shards=[self._blocks[f // self.FB] for f in range(self.F)])
+        self.gbs = self.launch._keepalive[4]
+        self.direct = bool(direct) and nranks > 1
         if nranks > 1:
             self.packed = torch.zeros((self.F, self.prow, W, 4), dtype=torch.uint8, device=dev)
             self._full_ptrs = (P * self.F)(*[g.color.data_ptr() for g in self.gbs])
             self._packed_ptrs = (P * self.F)(*[self.packed[f].data_ptr() for f in range(self.F)])
             self._root = None
+            if self.direct:
+                self._send = [self.packed, torch.zeros_like(self.packed)]
+                self._frames = []
+                frs = self.launch._keepalive[1]
+                for buf in self._send:
+                    tab = (_capi.Frame * self.F)()
+                    C.memmove(tab, frs, C.sizeof(tab))
+                    for f in range(self.F):
+                        tab[f].color8_strips = buf[f].data_ptr()
+                        if direct == "only":
+                            tab[f].color8 = None
+                    self._frames.append(tab)
+                self._cur = 1
             if self.owners:
                 self.finals = torch.zeros((self.FB, H, W, 4), dtype=torch.uint8, device=dev)
             elif rank == 0:
@@ -274,14 +299,17 @@ class ShardedBatch:
         return range(self.rank * self.FB, (self.rank + 1) * self.FB)
 
     def render(self, pushes):
-        """This rank's strips of every frame; returns the GeometryBuffers (own rows valid)."""
-        if self._blocks is None:
+        """This rank's strips of every frame; returns the GeometryBuffers (own rows valid).  direct: self.packed is the send
+        buffer this call filled."""
+        if not getattr(self, "direct", False):
             return self.launch(pushes)
-        for b, (ln, _) in enumerate(self._blocks):
-            ln(pushes[b * self.FB:(b + 1) * self.FB])
-        return self.gbs
+        self._cur ^= 1
+        self.packed = self._send[self._cur]
+        return self.launch(pushes, self._frames[self._cur])
 
     def pack(self):
+        if getattr(self, "direct", False):           # render() wrote the strips in place
+            return self.packed
         lib, ctx = _capi.lib(), self.stage.engine.ctx
         if self._blocks is None:
             _capi.check(lib.vrt_pack_rows_batch(ctx, self.F, self._full_ptrs, self._packed_ptrs, self.W, self.H, 4, C.byref(self.shard)))
@@ -290,7 +318,7 @@ class ShardedBatch:
         if getattr(self, "_pack_tabs", None) is None:      # per block: its slice of the pointer tables
             self._pack_tabs = [((P * self.FB)(*self._full_ptrs[b * self.FB:(b + 1) * self.FB]),
                                 (P * self.FB)(*self._packed_ptrs[b * self.FB:(b + 1) * self.FB])) for b in range(self.nranks)]
-        for (full, packed), (_, sh) in zip(self._pack_tabs, self._blocks):
+        for (full, packed), sh in zip(self._pack_tabs, self._blocks):
             _capi.check(lib.vrt_pack_rows_batch(ctx, self.FB, full, packed, self.W, self.H, 4, C.byref(sh)))
         return self.packed
 

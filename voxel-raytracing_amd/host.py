@@ -544,9 +544,10 @@ class GeometryStage:
         launch._keepalive = (st, fr, shard, gb)
         return launch
 
-    def prepare_batch(self, n: int, shard: Optional[_capi.Shard] = None):
+    def prepare_batch(self, n: int, shard: Optional[_capi.Shard] = None, shards=None):
         """n frames per launch (vrt_render_geometry_batch): consecutive poses of an animation or the frames of a multi-GPU
-        batch.  Returns launch(pushes) -> [GeometryBuffer] * n; every frame has its own planes, allocated here once."""
+        batch.  Returns launch(pushes) -> [GeometryBuffer] * n; every frame has its own planes, allocated here once.
+        shards: one strip assignment per frame instead of one for all (vrt_render_geometry_slots)."""
         W, H = self._settings.renderResolution()
         planes = GBUFFER_PLANES + (DEBUG_PLANES if self._debug else ())
         gbs = [GeometryBuffer(self.engine, W, H, planes) for _ in range(int(n))]
@@ -556,11 +557,18 @@ class GeometryStage:
         fn, ctx, scene = lib().vrt_render_geometry_batch, self.engine.ctx, self._scene.handle
         pst = C.byref(st)
         psh = C.byref(shard) if shard is not None else None
+        if shards is not None:
+            if len(shards) != int(n):
+                raise ValueError("prepare_batch: one shard per frame is required")
+            shard = (_capi.Shard * int(n))(*shards)
+            fn, psh = lib().vrt_render_geometry_slots, shard
 
-        def launch(pushes) -> list:
+        def launch(pushes, frames=None) -> list:
+            """frames: another (_capi.Frame * n) table to render into (e.g. a copy of launch._keepalive[1] with other
+            color8_strips pointers); default: the planes allocated above."""
             for k, p in enumerate(pushes):
                 arr[k] = p
-            rc = fn(ctx, scene, len(pushes), arr, pst, frs, psh)
+            rc = fn(ctx, scene, len(pushes), arr, pst, frs if frames is None else frames, psh)
             if rc != 0:
                 check(rc)
             return gbs[:len(pushes)]
