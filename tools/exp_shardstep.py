@@ -42,5 +42,13 @@ for N in (1, 2, 4, 8):
             al = timed(lambda: (sb.render(pushes), sb.assemble(), sb.pack()))
             line += f"  in sequence {al:.1f}"
         print(line, flush=True)
+        if True:
+            import time
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3): sb.render(pushes)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            print(f"      host time to enqueue one render(): {(t1 - t0) / 3 * 1e6:.0f} us", flush=True)
         del sb
         torch.cuda.empty_cache()
