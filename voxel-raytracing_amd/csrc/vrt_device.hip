@@ -388,8 +388,7 @@ template <> struct SlotOf<true> {
 // band per XCD leaves the XCDs that drew the sky idle), while the tiles of one row -- which walk neighbouring volume cells
 // -- still share that XCD's L2.
 //   xcd_turn == 0: per frame, row ty belongs to XCD ty % 8; ceil(rows / 8) * 8 row slots per frame (the surplus
-//                  workgroups exit at once).  The same rows of consecutive poses meet in the same L2 while two frames
-//                  overlap in the machine (worth 1 %).
+//                  workgroups exit at once).
 //   xcd_turn == 1: the rows of ALL frames of the launch are dealt round-robin in one sequence (row L = frame * rows + ty
 //                  to XCD L % 8).  For row counts far from a multiple of 8 -- a rank's 18 rows of a sharded 1080p frame
 //                  would be 3 rows for two XCDs and 2 for the others, and a third of the grid would be surplus -- the XCDs
