@@ -197,7 +197,7 @@ def main():
                     "frames_per_launch": frames_per_launch, "algorithmic_bytes_per_launch": int(b_alg),
                     "dda_steps_per_frame": S_frame, "steps_per_ray": round(S_frame / (W * H), 2)}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # the CPU leg is reported at N = 1 only
             from oracle import oracle                          # checker / CPU baseline only
             osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
             ncores = min(os.cpu_count() or 1, 16)
