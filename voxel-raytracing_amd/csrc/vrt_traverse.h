@@ -363,6 +363,50 @@ __device__ __forceinline__ void dda_advance_live_masks(DdaState& s, uint64_t liv
                  : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz), [lv] "s"(live)
                  : "vcc");
 }
+// A whole run of kw >= 1 iterations for the lanes of `live` in one block: kw - 1 iterations whose masks nobody reads, then
+// one that hands out its three EXEC masks.  EXEC is saved and put back once per run instead of once per iteration, and the
+// counter lives in the block: 5 scalar instructions per iteration (three EXEC reloads, decrement, branch) instead of 8.
+// The scalar unit matters: the kernel issues almost as many scalar as vector instructions.
+__device__ __forceinline__ void dda_run_live_masks(DdaState& s, uint64_t live, uint32_t kw, uint64_t& kx, uint64_t& ky, uint64_t& kz)
+{
+    uint32_t mn, cnt;
+    uint64_t entry;
+    asm volatile("s_mov_b64 %[en], exec\n\t"
+                 "s_sub_u32 %[cnt], %[kw], 2\n\t"            // kw - 2; borrow: no plain iteration
+                 "s_cbranch_scc1 2f\n\t"
+                 "1:\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[x]\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[y]\n\t"
+                 "v_add_f32 %[y], %[y], %[dy]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[z]\n\t"
+                 "v_add_f32 %[z], %[z], %[dz]\n\t"
+                 "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                 "s_cbranch_scc0 1b\n\t"
+                 "2:\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[x]\n\t"
+                 "s_mov_b64 %[kx], exec\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[y]\n\t"
+                 "s_mov_b64 %[ky], exec\n\t"
+                 "v_add_f32 %[y], %[y], %[dy]\n\t"
+                 "s_mov_b64 exec, %[lv]\n\t"
+                 "v_cmpx_eq_u32 %[mn], %[z]\n\t"
+                 "s_mov_b64 %[kz], exec\n\t"
+                 "v_add_f32 %[z], %[z], %[dz]\n\t"
+                 "s_mov_b64 exec, %[en]"
+                 : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [mn] "=&v"(mn), [en] "=&s"(entry), [cnt] "=&s"(cnt),
+                   [kx] "=&s"(kx), [ky] "=&s"(ky), [kz] "=&s"(kz)
+                 : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz), [lv] "s"(live), [kw] "s"(kw)
+                 : "vcc", "scc");
+}
 #endif
 
 // ---- wavefront votes (device: the 64 lanes of a gfx950 wave; host tests: a single lane) ------------------
@@ -561,9 +605,8 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             // accumulated rounding error is orders of magnitude below 1/2.
             const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
             // kw - 1 iterations whose mask nobody will read, then one whose EXEC masks are the mask bits
-            for (uint32_t j = 1; j < kw; j++) dda_advance_live(s, live);
             uint64_t kx, ky, kz;
-            dda_advance_live_masks(s, live, kx, ky, kz);
+            dda_run_live_masks(s, live, kw, kx, ky, kz);
             m0 = (m0 & ~live) | kx; m1 = (m1 & ~live) | ky; m2 = (m2 & ~live) | kz;
             const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
             s.mx += nx; s.my += ny; s.mz += nz;
