@@ -45,6 +45,7 @@ struct vrt_ctx {
     uint4* records = nullptr;
     uint32_t* hit_list = nullptr;     // [records_px] + 1 counter word at the end
     size_t records_px = 0;
+    int div_w = 0, div_h = 0, div_ok = 0;   // screen size last examined by screen_div_exact, and its verdict
     uint64_t checked_ptrs[2] = {0, 0};   // digests of the image pointers last verified to be device memory (geometry, denoiser)
     // frame-slot tables of launches with more than VRT_MAX_BATCH frames: a ring of device tables, each with a pinned host
     // image that is uploaded on a stream of its own (the copy runs while the previous launch is still tracing)
@@ -555,6 +556,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     memset(&p, 0, sizeof p);
     p.sc = s->d; p.st = *st;
     p.n_frames = n; p.W = W; p.H = H;
+    if (c->div_w != W || c->div_h != H) { c->div_ok = (screen_div_exact(W) && screen_div_exact(H)) ? 1 : 0; c->div_w = W; c->div_h = H; }
+    p.rcp_w = 1.0f / (float)W; p.rcp_h = 1.0f / (float)H; p.fast_screen_div = c->div_ok;
     int max_strips = 1;
     int rc = make_shard(shards, H, p.sh, &max_strips);
     if (rc != VRT_OK) return rc;

@@ -254,6 +254,40 @@ __device__ __forceinline__ f3 primary_dir(const FrameSlot& S, int px, int py)
     return normalize3(mk3(vx, vy, vz));
 }
 
+// primary_dir with fewer instructions (K1; an IEEE division expands to ~11 VALU instructions, and ray generation has five):
+//  * the two screen divisions by the 3-instruction sequence of screen_div_fast when the host found it exact for every
+//    pixel centre of this screen size (P.fast_screen_div);
+//  * normalize: the three divisions by the length share the reciprocal.  The instructions are those of the compiler's
+//    expansion of x / l without v_div_scale / v_div_fixup, which do nothing when numerator and denominator are normal
+//    numbers whose exponents differ by less than 96 and whose quotient is normal: guaranteed here for a whole wave by
+//    2^-40 <= min |component| and length <= 2^40 (a component never exceeds the length by more than rounding).  Any other
+//    wave -- zero components, huge or tiny camera vectors, NaN -- takes normalize3.
+__device__ __forceinline__ f3 primary_dir_fast(const GeomParams& P, const FrameSlot& S, int px, int py)
+{
+    const RayGenConsts& g = S.rg;
+    float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    float qx, qy;
+    if (P.fast_screen_div) { qx = screen_div_fast(fx, g.W, P.rcp_w); qy = screen_div_fast(fy, g.H, P.rcp_h); }
+    else                   { qx = fx / g.W; qy = fy / g.H; }
+    float sx = qx * 2.0f - 1.0f;
+    float sy = qy * 2.0f - 1.0f;
+    float vx = ((g.cd.x + sx * S.pc.cam_right[0]) + sy * g.planeV.x) + g.jx;
+    float vy = ((g.cd.y + sx * S.pc.cam_right[1]) + sy * g.planeV.y) + g.jy;
+    float vz = ((g.cd.z + sx * S.pc.cam_right[2]) + sy * g.planeV.z) + 0.0f;
+    const f3 v = mk3(vx, vy, vz);
+    const float l = len3(v);
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(vx), __builtin_fabsf(vy)), __builtin_fabsf(vz));
+    const bool tame = lo >= 0x1p-40f && l <= 0x1p40f;
+    if (__ballot(!tame) != 0ull) return normalize3(v);
+    const float r0 = __builtin_amdgcn_rcpf(l);
+    const float r = __builtin_fmaf(__builtin_fmaf(-l, r0, 1.0f), r0, r0);
+    f3 o;
+    { float q = vx * r; q = __builtin_fmaf(__builtin_fmaf(-l, q, vx), r, q); o.x = __builtin_fmaf(__builtin_fmaf(-l, q, vx), r, q); }
+    { float q = vy * r; q = __builtin_fmaf(__builtin_fmaf(-l, q, vy), r, q); o.y = __builtin_fmaf(__builtin_fmaf(-l, q, vy), r, q); }
+    { float q = vz * r; q = __builtin_fmaf(__builtin_fmaf(-l, q, vz), r, q); o.z = __builtin_fmaf(__builtin_fmaf(-l, q, vz), r, q); }
+    return o;
+}
+
 // calcAmbient + isShadowed + color + colorHit, voxel_volume.frag:205-264
 // SEC = false: the host has established ao_samples == 0 and shadows == 0 (K1 MODE 1), so neither loop is compiled in.
 template <int TRAV, class Occ, bool SEC = true>
@@ -475,7 +509,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
     const DevScene& s = P.sc;
     f3 start = mk3(S.pc.cam_pos[0], S.pc.cam_pos[1], S.pc.cam_pos[2]);
-    f3 dir = primary_dir(S, px, py);
+    f3 dir = primary_dir_fast(P, S, px, py);
     RayHit h; RayInt r;
     trace_ray<TRAV>(s, occ, start, dir, P.st.max_steps, h, r);
     bool hit = h.material != 0;

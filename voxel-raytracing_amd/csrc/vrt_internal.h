@@ -50,6 +50,25 @@ inline RayGenConsts raygen_consts(const vrt_push& pc)
     return g;
 }
 
+// (i + 0.5) / n for i in [0, n) as q = x * r; q += fma(-q, n, x) * r with r = 1 / n: one multiply and two FMAs instead of
+// the ~11 instructions of an IEEE division.  The sequence is the correctly rounded quotient for almost every divisor;
+// whether it is for THIS one is decided by trying all n numerators (the host does so once per screen size).
+__host__ __device__ inline float screen_div_fast(float x, float n, float r)
+{
+    float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, n, x), r, q);
+}
+inline bool screen_div_exact(int n)
+{
+    const float fn = (float)n, r = 1.0f / fn;
+    for (int i = 0; i < n; i++) {
+        const float x = (float)i + 0.5f;
+        volatile float want = x / fn;
+        if (screen_div_fast(x, fn, r) != want) return false;
+    }
+    return true;
+}
+
 // One frame of a launch: camera (push block + its hoisted part), output planes and the strip assignment it is traced
 // with (the rank of ShardMap; frames of one launch may play different ranks: vrt_render_geometry_slots).
 struct FrameSlot {
@@ -74,6 +93,8 @@ struct GeomParams {
     int32_t    xcd_turn;       // 1: tile rows of all frames are dealt to the XCDs in one sequence (block_to_tile)
     uint32_t   wgs_per_frame, wgs_per_frame_rcp;   // chunk * 8 and floor(2^32 / that)
     int32_t    W, H;                               // screen size (common to the frames)
+    float      rcp_w, rcp_h;                       // 1 / W, 1 / H
+    int32_t    fast_screen_div;                    // screen_div_fast is exact for every pixel centre of this W and H
     DevScene   sc;
     vrt_settings st;
     ShardMap   sh;

@@ -587,7 +587,11 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         // iterations the wave can take blind: the smallest clearance among its live lanes (the fields count the
         // outside of the volume as solid, so a run cannot carry a lane further than one voxel past a wall); the same
         // vote says whether anybody is still live
-        uint32_t kw = wave_min_vote(done ? VRT_VOTE_DONE : clear);     // live lanes stand on empty in-bounds voxels: >= 1
+        uint32_t vote = done ? VRT_VOTE_DONE : clear;                  // live lanes stand on empty in-bounds voxels: >= 1
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(vote));                                 // (keeps the compare below a compare: see `live`)
+#endif
+        uint32_t kw = wave_min_vote(vote);
         if (kw == VRT_VOTE_DONE) break;
         uint32_t left = maxSteps - i;                          // i < maxSteps for every live lane
         kw = kw < left ? kw : left;
@@ -599,7 +603,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             // lanes itself, so a finished lane's sideDist stands still, its differences below are 0 and its mapPos /
             // index do not move.  (Inside a divergent `if (!done)` the three lane masks would be per-lane values: six
             // VGPRs and twelve VALU ops per look-up to merge them.)
-            const uint64_t live = __ballot(!done);
+            const uint64_t live = __ballot(vote != VRT_VOTE_DONE);     // one compare; __ballot(!done) of the bool is two ops + a scalar one
             // Only sideDist is advanced inside the run; mapPos is recovered afterwards: an axis that took n steps has
             // grown by n (+) additions of delta, so n = round((side - side_before) / delta) -- n <= 63 per run and the
             // accumulated rounding error is orders of magnitude below 1/2.
