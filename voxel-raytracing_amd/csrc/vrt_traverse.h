@@ -371,20 +371,40 @@ __device__ __forceinline__ void dda_run_live_masks(DdaState& s, uint64_t live, u
 {
     uint32_t mn, cnt;
     uint64_t entry;
-    asm volatile("s_mov_b64 %[en], exec\n\t"
-                 "s_sub_u32 %[cnt], %[kw], 2\n\t"            // kw - 2; borrow: no plain iteration
-                 "s_cbranch_scc1 2f\n\t"
-                 "1:\n\t"
-                 "s_mov_b64 exec, %[lv]\n\t"
-                 "v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"
-                 "v_cmpx_eq_u32 %[mn], %[x]\n\t"
-                 "v_add_f32 %[x], %[x], %[dx]\n\t"
-                 "s_mov_b64 exec, %[lv]\n\t"
-                 "v_cmpx_eq_u32 %[mn], %[y]\n\t"
-                 "v_add_f32 %[y], %[y], %[dy]\n\t"
-                 "s_mov_b64 exec, %[lv]\n\t"
-                 "v_cmpx_eq_u32 %[mn], %[z]\n\t"
+#define VRT_DDA_ITER                                           \
+                 "s_mov_b64 exec, %[lv]\n\t"                    \
+                 "v_min3_u32 %[mn], %[x], %[y], %[z]\n\t"       \
+                 "v_cmpx_eq_u32 %[mn], %[x]\n\t"                \
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"              \
+                 "s_mov_b64 exec, %[lv]\n\t"                    \
+                 "v_cmpx_eq_u32 %[mn], %[y]\n\t"                \
+                 "v_add_f32 %[y], %[y], %[dy]\n\t"              \
+                 "s_mov_b64 exec, %[lv]\n\t"                    \
+                 "v_cmpx_eq_u32 %[mn], %[z]\n\t"                \
                  "v_add_f32 %[z], %[z], %[dz]\n\t"
+    // half of all runs are a single iteration: they take the first branch and nothing else; longer runs do their plain
+    // iterations four per loop trip (a taken branch stalls the wave's instruction stream), the odd one, two or three first
+    asm volatile("s_mov_b64 %[en], exec\n\t"
+                 "s_cmp_eq_u32 %[kw], 1\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_sub_u32 %[cnt], %[kw], 1\n\t"            // plain iterations, >= 1
+                 "s_bitcmp0_b32 %[cnt], 0\n\t"
+                 "s_cbranch_scc1 3f\n\t"
+                 VRT_DDA_ITER
+                 "3:\n\t"
+                 "s_bitcmp0_b32 %[cnt], 1\n\t"
+                 "s_cbranch_scc1 4f\n\t"
+                 VRT_DDA_ITER
+                 VRT_DDA_ITER
+                 "4:\n\t"
+                 "s_lshr_b32 %[cnt], %[cnt], 2\n\t"          // quads; SCC = (quads != 0)
+                 "s_cbranch_scc0 2f\n\t"
+                 "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                 "1:\n\t"
+                 VRT_DDA_ITER
+                 VRT_DDA_ITER
+                 VRT_DDA_ITER
+                 VRT_DDA_ITER
                  "s_sub_u32 %[cnt], %[cnt], 1\n\t"
                  "s_cbranch_scc0 1b\n\t"
                  "2:\n\t"
@@ -406,6 +426,7 @@ __device__ __forceinline__ void dda_run_live_masks(DdaState& s, uint64_t live, u
                    [kx] "=&s"(kx), [ky] "=&s"(ky), [kz] "=&s"(kz)
                  : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz), [lv] "s"(live), [kw] "s"(kw)
                  : "vcc", "scc");
+#undef VRT_DDA_ITER
 }
 #endif
 
