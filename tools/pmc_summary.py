@@ -11,7 +11,8 @@ kernel = sys.argv[2] if len(sys.argv) > 2 else "k_primary<4"
 frames_per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 out = {}
 for d in sorted(glob.glob("gpurun_out/pmc_*/")):
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:               # gpurun merges every run into the same directory: the newest file is this run's
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"]:
