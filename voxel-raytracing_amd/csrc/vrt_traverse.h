@@ -587,12 +587,22 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
     uint32_t i = 0;                                            // wave-uniform: every live lane has done i iterations
     uint32_t n_outer = 0, n_long = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the clearance of the next look-up is requested as soon as its index is known, at the end of the loop body, by every
+    // lane (a finished lane re-reads the byte it stopped at): the mask merges, position updates and the loop's scalar
+    // bookkeeping then run while the byte is on its way instead of before the request
+    uint32_t ahead = v.df[idx];
+#endif
     for (;;) {
         n_outer++;
         if (!done) {
             if (i >= maxSteps) { done = true; fetches = i; }
             else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                clear = ahead;
+#else
                 clear = v.df[idx];
+#endif
                 st_lookup(stats);
                 if (clear == 0u) {                             // solid, or the border: the ray has left the volume
                     if (oob(v, s.mx, s.my, s.mz)) fetches = i;
@@ -632,11 +642,12 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             // kw - 1 iterations whose mask nobody will read, then one whose EXEC masks are the mask bits
             uint64_t kx, ky, kz;
             dda_run_live_masks(s, live, kw, kx, ky, kz);
-            m0 = (m0 & ~live) | kx; m1 = (m1 & ~live) | ky; m2 = (m2 & ~live) | kz;
             const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
-            s.mx += nx; s.my += ny; s.mz += nz;
             idx += SMALL ? (IDX)(nx + mul24(ny, pw) + mul24(nz, (int)pwh))
                          : (IDX)((SIDX)nx + (SIDX)ny * (SIDX)pw + (SIDX)nz * (SIDX)pwh);
+            ahead = v.df[idx];
+            s.mx += nx; s.my += ny; s.mz += nz;
+            m0 = (m0 & ~live) | kx; m1 = (m1 & ~live) | ky; m2 = (m2 & ~live) | kz;
         }
 #else
         if (!done) {
