@@ -165,11 +165,11 @@ __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 }
 
 // traceRay, voxel_volume.frag:176-196
-template <int TRAV, class Occ>
+template <int TRAV, class Occ, bool AHEAD = false>
 __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 start, f3 dir,
                                           uint32_t maxSteps, RayHit& h, RayInt& r)
 {
-    trace_int<TRAV>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
+    trace_int<TRAV, decltype(occ.o2), AHEAD>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
     h.material = r.material;
     h.dir = dir;
     // values first, one assignment to h afterwards: stores to h from both sides of the branch were being merged into
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     f3 start = mk3(S.pc.cam_pos[0], S.pc.cam_pos[1], S.pc.cam_pos[2]);
     f3 dir = primary_dir_fast(P, S, px, py);
     RayHit h; RayInt r;
-    trace_ray<TRAV>(s, occ, start, dir, P.st.max_steps, h, r);
+    trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
     bool hit = h.material != 0;
 
     const vrt_frame f = S.fr;                 // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store

@@ -541,7 +541,7 @@ VRT_HD uint32_t wave_min_vote(uint32_t k)
 // that many iterations of pure ALU stepping -- the same fp32 additions as the shader, hence bit-identical
 // results -- then look at memory again.  Neighbouring rays have similar clearances, so the wave-wide minimum
 // costs little.  Finished lanes are masked off; the votes see live lanes only.
-template <bool SMALL, class STATS>
+template <bool SMALL, class STATS, bool AHEAD>
 VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -590,8 +590,10 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 #if defined(__HIP_DEVICE_COMPILE__)
     // the clearance of the next look-up is requested as soon as its index is known, at the end of the loop body, by every
     // lane (a finished lane re-reads the byte it stopped at): the mask merges, position updates and the loop's scalar
-    // bookkeeping then run while the byte is on its way instead of before the request
-    uint32_t ahead = v.df[idx];
+    // bookkeeping then run while the byte is on its way instead of before the request.  AHEAD: primary rays of the
+    // primary-only kernel; in the megakernel the extra request per ray costs the short secondary rays more than it hides
+    // (+15 % on the reference defaults).
+    uint32_t ahead = AHEAD ? v.df[idx] : 0u;
 #endif
     for (;;) {
         n_outer++;
@@ -599,7 +601,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             if (i >= maxSteps) { done = true; fetches = i; }
             else {
 #if defined(__HIP_DEVICE_COMPILE__)
-                clear = ahead;
+                clear = AHEAD ? ahead : (uint32_t)v.df[idx];
 #else
                 clear = v.df[idx];
 #endif
@@ -645,7 +647,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
             idx += SMALL ? (IDX)(nx + mul24(ny, pw) + mul24(nz, (int)pwh))
                          : (IDX)((SIDX)nx + (SIDX)ny * (SIDX)pw + (SIDX)nz * (SIDX)pwh);
-            ahead = v.df[idx];
+            if (AHEAD) ahead = v.df[idx];
             s.mx += nx; s.my += ny; s.mz += nz;
             m0 = (m0 & ~live) | kx; m1 = (m1 & ~live) | ky; m2 = (m2 & ~live) | kz;
         }
@@ -679,13 +681,13 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     r.dbg0 = n_outer; r.dbg1 = n_long;
 }
 
-template <class STATS>
+template <class STATS, bool AHEAD = false>
 VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     // wave-uniform choice; the 64-bit variant is only reached by volumes whose eight fields total 4 GiB or more (or
     // whose padded z-slice does not fit the 24-bit multiply of the incremental index)
-    if (df_small(v)) trace_df_impl<true>(v, start, dir, maxSteps, r, stats);
-    else trace_df_impl<false>(v, start, dir, maxSteps, r, stats);
+    if (df_small(v)) trace_df_impl<true, STATS, AHEAD>(v, start, dir, maxSteps, r, stats);
+    else trace_df_impl<false, STATS, AHEAD>(v, start, dir, maxSteps, r, stats);
 }
 
 // DENSE: one R8 fetch per iteration.  Straight-line body with a single exit (out of budget, out of bounds or
@@ -1022,7 +1024,7 @@ VRT_HD void trace_dfj(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, 
 }
 
 // Dispatcher used by the kernels.
-template <int TRAV, class OP>
+template <int TRAV, class OP, bool AHEAD = false>
 VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
                       uint32_t maxSteps, RayInt& r)
 {
@@ -1031,7 +1033,7 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
         trace_jump(v, o2, o3, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF) {
         NoStats ns;
-        trace_df(v, start, dir, maxSteps, r, ns);
+        trace_df<NoStats, AHEAD>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DFJ) {
         NoStats ns;
         trace_dfj(v, start, dir, maxSteps, r, ns);
