@@ -586,7 +586,15 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     // signed steps per unit of sideDist: dir is 1/(+-delta) to within an ulp; 0 for an axis that cannot step
     const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
     uint32_t i = 0;                                            // wave-uniform: every live lane has done i iterations
-    uint32_t n_outer = 0, n_long = 0;
+    // look-ups and iterations in runs of >= 12: host instrumentation; on the device only in development builds
+    // (make HIPFLAGS+=-DVRT_TRACE_COUNTERS for tools/exp_wavecost.py, exp_skipstats.py) -- four scalar instructions per
+    // look-up in a kernel whose scalar unit is not idle
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(VRT_TRACE_COUNTERS)
+#define VRT_DF_COUNT(x) x
+#else
+#define VRT_DF_COUNT(x)
+#endif
+    VRT_DF_COUNT(uint32_t n_outer = 0; uint32_t n_long = 0;)
 #if defined(__HIP_DEVICE_COMPILE__)
     // the clearance of the next look-up is requested as soon as its index is known, at the end of the loop body, by every
     // lane (a finished lane re-reads the byte it stopped at): the mask merges, position updates and the loop's scalar
@@ -596,7 +604,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     uint32_t ahead = AHEAD ? v.df[idx] : 0u;
 #endif
     for (;;) {
-        n_outer++;
+        VRT_DF_COUNT(n_outer++;)
         if (!done) {
             if (i >= maxSteps) { done = true; fetches = i; }
             else {
@@ -629,7 +637,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         uint32_t left = maxSteps - i;                          // i < maxSteps for every live lane
         kw = kw < left ? kw : left;
         st_jump(stats, kw > 4u ? 2 : 1);
-        if (kw >= 12u) n_long += kw;
+        VRT_DF_COUNT(if (kw >= 12u) n_long += kw;)
 #if defined(__HIP_DEVICE_COMPILE__)
         {
             // The run is wave-uniform control flow: every lane executes it, but the stepping asm narrows EXEC to the live
@@ -678,7 +686,8 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 #else
     finish(s, material, (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2), fetches, r);
 #endif
-    r.dbg0 = n_outer; r.dbg1 = n_long;
+    VRT_DF_COUNT(r.dbg0 = n_outer; r.dbg1 = n_long;)
+#undef VRT_DF_COUNT
 }
 
 template <class STATS, bool AHEAD = false>
