@@ -618,6 +618,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     // primary-only kernel; in the megakernel the extra request per ray costs the short secondary rays more than it hides
     // (+15 % on the reference defaults).
     uint32_t ahead = AHEAD ? v.df[idx] : 0u;
+    if (AHEAD && maxSteps == 0u) done = true;                  // (fetches = 0: no iteration runs)
 #endif
     for (;;) {
         VRT_DF_COUNT(n_outer++;)
@@ -626,22 +627,18 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         // enter divergent code -- not a divergent `if (!done)` around everything, whose EXEC bookkeeping is a dozen scalar
         // instructions per look-up.
         // (Primary rays of the primary-only kernel, like the look-ahead request: the megakernel loses 10 % with it.)
-        if (AHEAD) {
-            if (i >= maxSteps) {
-                if (!done) { done = true; fetches = i; lmask = lane_bits(kx, ky, kz); }
-            } else {
-                clear = ahead;
-                st_lookup(stats);
-                if (!done && clear == 0u) {                    // solid, or the border: the ray has left the volume
-                    if (oob(v, s.mx, s.my, s.mz)) fetches = i;
-                    else {
-                        material = SMALL ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
-                                         : voxel_at(v, s.mx, s.my, s.mz);
-                        fetches = i + 1u;
-                    }
-                    done = true;
-                    lmask = lane_bits(kx, ky, kz);
+        if (AHEAD) {                                           // i < maxSteps here: the budget is tested where i grows
+            clear = ahead;
+            st_lookup(stats);
+            if (!done && clear == 0u) {                        // solid, or the border: the ray has left the volume
+                if (oob(v, s.mx, s.my, s.mz)) fetches = i;
+                else {
+                    material = SMALL ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
+                                     : voxel_at(v, s.mx, s.my, s.mz);
+                    fetches = i + 1u;
                 }
+                done = true;
+                lmask = lane_bits(kx, ky, kz);
             }
         } else if (!done) {
             if (i >= maxSteps) { done = true; fetches = i; lmask = lane_bits(kx, ky, kz); }
@@ -729,6 +726,12 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         }
 #endif
         i += kw;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (AHEAD && i >= maxSteps) {                          // wave-uniform: the budget ends for every live lane at once
+            if (!done) { fetches = i; lmask = lane_bits(kx, ky, kz); }
+            break;
+        }
+#endif
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     finish(s, material, lmask, fetches, r);
