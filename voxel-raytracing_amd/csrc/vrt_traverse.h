@@ -627,18 +627,27 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         // enter divergent code -- not a divergent `if (!done)` around everything, whose EXEC bookkeeping is a dozen scalar
         // instructions per look-up.
         // (Primary rays of the primary-only kernel, like the look-ahead request: the megakernel loses 10 % with it.)
+        uint32_t vote;
         if (AHEAD) {                                           // i < maxSteps here: the budget is tested where i grows
             clear = ahead;
             st_lookup(stats);
-            if (!done && clear == 0u) {                        // solid, or the border: the ray has left the volume
-                if (oob(v, s.mx, s.my, s.mz)) fetches = i;
-                else {
-                    material = SMALL ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
-                                     : voxel_at(v, s.mx, s.my, s.mz);
-                    fetches = i + 1u;
+            // the vote value first: a live lane that found 0 is the one lane whose vote is 0, so "did anybody hit" is one
+            // compare and a wave-uniform branch that falls through when nobody did (no s_and_saveexec / taken branch /
+            // s_or exec around a divergent region in the common case)
+            vote = done ? VRT_VOTE_DONE : clear;
+            asm volatile("" : "+v"(vote));
+            if (__builtin_expect(__ballot(vote == 0u) != 0ull, 0)) {
+                if (vote == 0u) {                              // solid, or the border: the ray has left the volume
+                    if (oob(v, s.mx, s.my, s.mz)) fetches = i;
+                    else {
+                        material = SMALL ? v.vox[(uint32_t)s.mx + ((uint32_t)s.my + (uint32_t)s.mz * (uint32_t)v.H) * (uint32_t)v.W]
+                                         : voxel_at(v, s.mx, s.my, s.mz);
+                        fetches = i + 1u;
+                    }
+                    done = true;
+                    lmask = lane_bits(kx, ky, kz);
+                    vote = VRT_VOTE_DONE;
                 }
-                done = true;
-                lmask = lane_bits(kx, ky, kz);
             }
         } else if (!done) {
             if (i >= maxSteps) { done = true; fetches = i; lmask = lane_bits(kx, ky, kz); }
@@ -678,9 +687,11 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
         // iterations the wave can take blind: the smallest clearance among its live lanes (the fields count the
         // outside of the volume as solid, so a run cannot carry a lane further than one voxel past a wall); the same
         // vote says whether anybody is still live
-        uint32_t vote = done ? VRT_VOTE_DONE : clear;                  // live lanes stand on empty in-bounds voxels: >= 1
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (!AHEAD) vote = done ? VRT_VOTE_DONE : clear;               // live lanes stand on empty in-bounds voxels: >= 1
         asm volatile("" : "+v"(vote));                                 // (keeps the compare below a compare: see `live`)
+#else
+        uint32_t vote = done ? VRT_VOTE_DONE : clear;
 #endif
         uint32_t kw = wave_min_vote(vote);
         if (kw == VRT_VOTE_DONE) break;
