@@ -624,6 +624,14 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         HIPCHK(hipMemsetAsync(p.hit_count, 0, sizeof(uint32_t), c->stream));
     }
     if (p.total_tiles == 0) return VRT_OK;
+    {
+        TileMap& m = p.map;
+        m.flags = st->flags; m.n_frames = p.n_frames; m.xcd_turn = p.xcd_turn;
+        m.wgs_per_frame = p.wgs_per_frame; m.wgs_per_frame_rcp = p.wgs_per_frame_rcp;
+        m.tiles_x = p.tiles_x; m.tiles_x_rcp = p.tiles_x_rcp; m.tiles_y_local = p.tiles_y_local; m.tiles_y_rcp = p.tiles_y_rcp;
+        m.tps = p.tps; m.tps_rcp = p.tps_rcp; m.tile = p.tile_h; m.nranks = p.sh.nranks; m.strip_rows = p.sh.strip_rows;
+        m.W = p.W; m.H = p.H;
+    }
     if (tab >= 0) {
         HIPCHK(hipMemcpyAsync(c->tab_dev[tab], c->tab_host[tab], sizeof(FrameSlot) * (size_t)n, hipMemcpyHostToDevice, c->upload_stream));
         HIPCHK(hipEventRecord(c->tab_uploaded[tab], c->upload_stream));

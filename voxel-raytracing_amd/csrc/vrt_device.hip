@@ -262,18 +262,18 @@ __device__ __forceinline__ f3 primary_dir(const FrameSlot& S, int px, int py)
 //    numbers whose exponents differ by less than 96 and whose quotient is normal: guaranteed here for a whole wave by
 //    2^-40 <= min |component| and length <= 2^40 (a component never exceeds the length by more than rounding).  Any other
 //    wave -- zero components, huge or tiny camera vectors, NaN -- takes normalize3.
-__device__ __forceinline__ f3 primary_dir_fast(const GeomParams& P, const FrameSlot& S, int px, int py)
+__device__ __forceinline__ f3 primary_dir_fast(const RayGenConsts& g, float crx, float cry, float crz, float rcp_w, float rcp_h,
+                                               int fast_screen_div, int px, int py)
 {
-    const RayGenConsts& g = S.rg;
     float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     float qx, qy;
-    if (P.fast_screen_div) { qx = screen_div_fast(fx, g.W, P.rcp_w); qy = screen_div_fast(fy, g.H, P.rcp_h); }
-    else                   { qx = fx / g.W; qy = fy / g.H; }
+    if (fast_screen_div) { qx = screen_div_fast(fx, g.W, rcp_w); qy = screen_div_fast(fy, g.H, rcp_h); }
+    else                 { qx = fx / g.W; qy = fy / g.H; }
     float sx = qx * 2.0f - 1.0f;
     float sy = qy * 2.0f - 1.0f;
-    float vx = ((g.cd.x + sx * S.pc.cam_right[0]) + sy * g.planeV.x) + g.jx;
-    float vy = ((g.cd.y + sx * S.pc.cam_right[1]) + sy * g.planeV.y) + g.jy;
-    float vz = ((g.cd.z + sx * S.pc.cam_right[2]) + sy * g.planeV.z) + 0.0f;
+    float vx = ((g.cd.x + sx * crx) + sy * g.planeV.x) + g.jx;
+    float vy = ((g.cd.y + sx * cry) + sy * g.planeV.y) + g.jy;
+    float vz = ((g.cd.z + sx * crz) + sy * g.planeV.z) + 0.0f;
     const f3 v = mk3(vx, vy, vz);
     const float l = len3(v);
     const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(vx), __builtin_fabsf(vy)), __builtin_fabsf(vz));
@@ -427,33 +427,33 @@ template <> struct SlotOf<true> {
 //                  to XCD L % 8).  For row counts far from a multiple of 8 -- a rank's 18 rows of a sharded 1080p frame
 //                  would be 3 rows for two XCDs and 2 for the others, and a third of the grid would be surplus -- the XCDs
 //                  stay even and only the last seven row slots of the launch can be empty.
-__device__ __forceinline__ bool block_to_tile(const GeomParams& P, uint32_t& frame, int& ty, int& tx)
+__device__ __forceinline__ bool block_to_tile(const TileMap& M, uint32_t& frame, int& ty, int& tx)
 {
     uint32_t b = blockIdx.x, utx;
     frame = 0;
-    if (P.xcd_turn) {
-        uint32_t L = udiv_uniform(b >> 3, (uint32_t)P.tiles_x, P.tiles_x_rcp, utx) * 8u + (b & 7u), uty;
-        frame = udiv_uniform(L, (uint32_t)P.tiles_y_local, P.tiles_y_rcp, uty);
+    if (M.xcd_turn) {
+        uint32_t L = udiv_uniform(b >> 3, (uint32_t)M.tiles_x, M.tiles_x_rcp, utx) * 8u + (b & 7u), uty;
+        frame = udiv_uniform(L, (uint32_t)M.tiles_y_local, M.tiles_y_rcp, uty);
         ty = (int)uty; tx = (int)utx;
-        return frame < (uint32_t)P.n_frames;
+        return frame < (uint32_t)M.n_frames;
     }
-    if (P.n_frames > 1) frame = udiv_uniform(blockIdx.x, P.wgs_per_frame, P.wgs_per_frame_rcp, b);
-    ty = (int)(udiv_uniform(b >> 3, (uint32_t)P.tiles_x, P.tiles_x_rcp, utx) * 8u + (b & 7u)); tx = (int)utx;
-    return ty < P.tiles_y_local;
+    if (M.n_frames > 1) frame = udiv_uniform(blockIdx.x, M.wgs_per_frame, M.wgs_per_frame_rcp, b);
+    ty = (int)(udiv_uniform(b >> 3, (uint32_t)M.tiles_x, M.tiles_x_rcp, utx) * 8u + (b & 7u)); tx = (int)utx;
+    return ty < M.tiles_y_local;
 }
 
 // yp0: the row of y0 in the rank's packed strips (vrt_pack_rows order)
-__device__ __forceinline__ bool tile_origin(const GeomParams& P, int ty, int tx, int shard_rank, int& x0, int& y0, int& yp0)
+__device__ __forceinline__ bool tile_origin(const TileMap& M, int ty, int tx, int shard_rank, int& x0, int& y0, int& yp0)
 {
     // bottom rows first: the rows dispatched last only have the drain of the machine to hide in, and the top of a
     // frame is where the cheap sky-only tiles usually are
-    ty = P.tiles_y_local - 1 - ty;
+    ty = M.tiles_y_local - 1 - ty;
     uint32_t within;
-    int strip_local = (int)udiv_uniform((uint32_t)ty, P.tps, P.tps_rcp, within);
-    x0 = tx * P.tile_w;
-    yp0 = strip_local * P.sh.strip_rows + (int)within * P.tile_h;
-    y0 = (strip_local * P.sh.nranks + shard_rank) * P.sh.strip_rows + (int)within * P.tile_h;
-    return y0 < P.H;
+    int strip_local = (int)udiv_uniform((uint32_t)ty, M.tps, M.tps_rcp, within);
+    x0 = tx * M.tile;
+    yp0 = strip_local * M.strip_rows + (int)within * M.tile;
+    y0 = (strip_local * M.nranks + shard_rank) * M.strip_rows + (int)within * M.tile;
+    return y0 < M.H;
 }
 
 // Stage the 16^3 and 64^3 occupancy summaries into LDS (16 B per lane per iteration, coalesced).
@@ -488,12 +488,30 @@ template <int TRAV, bool OCC_LDS, int MODE, bool TABLE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_primary(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
-    const uint64_t t_begin = (P.st.flags & 2u) ? wall_clock64() : 0ull;      // diagnostic timeline (100 MHz)
+    // the tile map arrives with one 64-byte scalar load (and one wait) before anything depends on it
+    TileMap M = P.map;
+    asm volatile("" : "+s"(M.flags), "+s"(M.n_frames), "+s"(M.xcd_turn), "+s"(M.wgs_per_frame), "+s"(M.wgs_per_frame_rcp),
+                      "+s"(M.tiles_x), "+s"(M.tiles_x_rcp), "+s"(M.tiles_y_local), "+s"(M.tiles_y_rcp), "+s"(M.tps),
+                      "+s"(M.tps_rcp), "+s"(M.tile), "+s"(M.nranks), "+s"(M.strip_rows), "+s"(M.W), "+s"(M.H));
+    const uint64_t t_begin = (M.flags & 2u) ? wall_clock64() : 0ull;         // diagnostic timeline (100 MHz)
     int x0, y0, yp0, ty, tx;
     uint32_t frame;
-    if (!block_to_tile(P, frame, ty, tx)) return;                        // uniform per workgroup
+    if (!block_to_tile(M, frame, ty, tx)) return;                        // uniform per workgroup
     typename SlotOf<TABLE>::type S = SlotOf<TABLE>::get(P, frame);
-    if (!tile_origin(P, ty, tx, S.shard_rank, x0, y0, yp0)) return;
+    // ... and so does the frame's part of ray generation (camera, hoisted constants, strip assignment), in one batch
+    RayGenConsts g = S.rg;
+    float cpx = S.pc.cam_pos[0], cpy = S.pc.cam_pos[1], cpz = S.pc.cam_pos[2];
+    float crx = S.pc.cam_right[0], cry = S.pc.cam_right[1], crz = S.pc.cam_right[2];
+    int shard_rank = S.shard_rank;
+    float rcp_w = P.rcp_w, rcp_h = P.rcp_h;
+    int fast_div = P.fast_screen_div;
+    asm volatile("" : "+s"(g.cd.x), "+s"(g.cd.y), "+s"(g.cd.z), "+s"(g.planeV.x), "+s"(g.planeV.y), "+s"(g.planeV.z), "+s"(g.jx), "+s"(g.jy),
+                      "+s"(g.W), "+s"(g.H), "+s"(cpx), "+s"(cpy), "+s"(cpz), "+s"(crx), "+s"(cry), "+s"(crz), "+s"(shard_rank),
+                      "+s"(rcp_w), "+s"(rcp_h), "+s"(fast_div));
+    // (the scene scalars the DDA set-up will ask for one by one: requested here, used from these registers later)
+    asm volatile("" :: "s"(P.sc.vol.W), "s"(P.sc.vol.H), "s"(P.sc.vol.D), "s"(P.st.max_steps), "s"(P.sc.vol.df), "s"(P.sc.vol.df_stride),
+                       "s"(P.sc.vol.vox));
+    if (!tile_origin(M, ty, tx, shard_rank, x0, y0, yp0)) return;
     constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
     const OccT<kLds> occ = stage_occ<kLds>(P, lds_occ);
 
@@ -503,13 +521,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int px = x0 + (wave & 1) * 8 + (lane & 7);
     int py = y0 + (wave >> 1) * 8 + (lane >> 3);
-    int W = P.W, H = P.H;
+    int W = M.W, H = M.H;
     if (px >= W || py >= H) return;
     size_t i = (size_t)py * (size_t)W + (size_t)px;
 
     const DevScene& s = P.sc;
-    f3 start = mk3(S.pc.cam_pos[0], S.pc.cam_pos[1], S.pc.cam_pos[2]);
-    f3 dir = primary_dir_fast(P, S, px, py);
+    f3 start = mk3(cpx, cpy, cpz);
+    f3 dir = primary_dir_fast(g, crx, cry, crz, rcp_w, rcp_h, fast_div, px, py);
     RayHit h; RayInt r;
     trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
     bool hit = h.material != 0;

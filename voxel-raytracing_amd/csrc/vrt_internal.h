@@ -83,11 +83,27 @@ static_assert(sizeof(FrameSlot) == 256, "FrameSlot is sized for aligned scalar l
 #define VRT_MAX_BATCH 8      // frames per K1 launch whose slots travel in the kernel arguments (8 x 256 B)
 #define VRT_MAX_TABLE 256    // frames per K1 launch whose slots are read from a table in device memory
 
+// Everything a workgroup needs to find its tile, in one 64-byte block of the kernel arguments: a wave fetches it with one
+// scalar load and one wait instead of ten loads of one or two dwords, each waited for before the next could be issued.
+struct alignas(64) TileMap {
+    uint32_t flags;                    // vrt_settings.flags
+    int32_t  n_frames, xcd_turn;
+    uint32_t wgs_per_frame, wgs_per_frame_rcp;
+    int32_t  tiles_x;       uint32_t tiles_x_rcp;
+    int32_t  tiles_y_local; uint32_t tiles_y_rcp;
+    uint32_t tps, tps_rcp;
+    int32_t  tile;                     // tile_w == tile_h
+    int32_t  nranks, strip_rows;
+    int32_t  W, H;
+};
+static_assert(sizeof(TileMap) == 64, "TileMap is one 16-dword scalar load");
+
 struct GeomParams {
     // A launch covers n_frames frames of one scene, one resolution and one set of settings (consecutive camera poses of an
     // animation, or the frames of a multi-GPU batch): workgroup b works on frame b / wgs_per_frame.  Frame f+1's tiles are
     // dispatched while frame f drains, so the ~30 us tail of a frame is paid once per launch instead of once per frame.
     FrameSlot  slot[VRT_MAX_BATCH];
+    TileMap    map;            // copies of the fields below that the tile mapping reads (filled last by the host)
     const FrameSlot* table;    // non-null: n_frames (<= VRT_MAX_TABLE) slots in device memory instead of slot[]
     int32_t    n_frames;
     int32_t    xcd_turn;       // 1: tile rows of all frames are dealt to the XCDs in one sequence (block_to_tile)
