@@ -367,7 +367,8 @@ __device__ __forceinline__ void dda_advance_live_masks(DdaState& s, uint64_t liv
 // one that hands out its three EXEC masks.  EXEC is saved and put back once per run instead of once per iteration, and the
 // counter lives in the block: 5 scalar instructions per iteration (three EXEC reloads, decrement, branch) instead of 8.
 // The scalar unit matters: the kernel issues almost as many scalar as vector instructions.
-__device__ __forceinline__ void dda_run_live_masks(DdaState& s, uint64_t live, uint32_t kw, uint64_t& kx, uint64_t& ky, uint64_t& kz)
+__device__ __forceinline__ void dda_run_live_masks(DdaState& s, uint64_t live, uint32_t kw, uint64_t& kx, uint64_t& ky, uint64_t& kz,
+                                                   float& ox, float& oy, float& oz)
 {
     uint32_t mn, cnt;
     uint64_t entry;
@@ -384,7 +385,12 @@ __device__ __forceinline__ void dda_run_live_masks(DdaState& s, uint64_t live, u
                  "v_add_f32 %[z], %[z], %[dz]\n\t"
     // half of all runs are a single iteration: they take the first branch and nothing else; longer runs do their plain
     // iterations four per loop trip (a taken branch stalls the wave's instruction stream), the odd one, two or three first
+    // (the block also keeps sideDist as it was on entry, ox/oy/oz: the compiler's own copies around an in/out operand are
+    // three before and two after)
     asm volatile("s_mov_b64 %[en], exec\n\t"
+                 "v_mov_b32 %[ox], %[x]\n\t"
+                 "v_mov_b32 %[oy], %[y]\n\t"
+                 "v_mov_b32 %[oz], %[z]\n\t"
                  "s_cmp_eq_u32 %[kw], 1\n\t"
                  "s_cbranch_scc1 2f\n\t"
                  "s_sub_u32 %[cnt], %[kw], 1\n\t"            // plain iterations, >= 1
@@ -423,7 +429,7 @@ __device__ __forceinline__ void dda_run_live_masks(DdaState& s, uint64_t live, u
                  "v_add_f32 %[z], %[z], %[dz]\n\t"
                  "s_mov_b64 exec, %[en]"
                  : [x] "+v"(s.sdx), [y] "+v"(s.sdy), [z] "+v"(s.sdz), [mn] "=&v"(mn), [en] "=&s"(entry), [cnt] "=&s"(cnt),
-                   [kx] "=&s"(kx), [ky] "=&s"(ky), [kz] "=&s"(kz)
+                   [kx] "=&s"(kx), [ky] "=&s"(ky), [kz] "=&s"(kz), [ox] "=&v"(ox), [oy] "=&v"(oy), [oz] "=&v"(oz)
                  : [dx] "v"(s.dx), [dy] "v"(s.dy), [dz] "v"(s.dz), [lv] "s"(live), [kw] "s"(kw)
                  : "vcc", "scc");
 #undef VRT_DDA_ITER
@@ -709,9 +715,9 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
             // Only sideDist is advanced inside the run; mapPos is recovered afterwards: an axis that took n steps has
             // grown by n (+) additions of delta, so n = round((side - side_before) / delta) -- n <= 63 per run and the
             // accumulated rounding error is orders of magnitude below 1/2.
-            const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
+            float ox, oy, oz;
             // kw - 1 iterations whose mask nobody will read, then one whose EXEC masks are the mask bits
-            dda_run_live_masks(s, live, kw, kx, ky, kz);
+            dda_run_live_masks(s, live, kw, kx, ky, kz, ox, oy, oz);
             const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
             idx += SMALL ? (IDX)(nx + mul24(ny, pw) + mul24(nz, (int)pwh))
                          : (IDX)((SIDX)nx + (SIDX)ny * (SIDX)pw + (SIDX)nz * (SIDX)pwh);
