@@ -249,3 +249,40 @@ def test_color8_strips_is_the_packed_colour(vrt, engine, mode):
                 want[torch.from_numpy(rm < 0).cuda()] = 77                       # padding rows: untouched by the kernel
             assert (strips[f] == want).all(), (mode, shard is not None and shard.rank, f)
         assert strips.ne(77).any()
+
+
+def test_side_stream_unpack_assembles_the_same_frames(vrt, engine):
+    """ShardedBatch(side_unpack=True): finish() hands the unpack to a second stream (with a context of its own) and the
+    launch stream only waits for the arrival event.  Three steps with the all-to-all replaced by device copies and a work
+    object whose wait() has nothing to wait for; the receive buffers are reused every step, so the copies play the role of
+    the next collective and take the same guard (wait for the previous unpack)."""
+    vol = vrt.synthetic.treehouse(48, seed=6)
+    sc = vrt.VoxelScene.from_dense(engine, vol, vrt.synthetic.default_palette(), sky=vrt.synthetic.sky_gradient(64, 32))
+    res, N, FB = (208, 136), 3, 2
+    F = N * FB
+    st = vrt.VoxelRenderSettings.primary_only(res)
+
+    class Arrived:
+        def wait(self):
+            pass
+
+    ranks = [vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, r, N, assemble_on="owners", side_unpack=True) for r in range(N)]
+    alone = vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, 0, 1)
+    recv = [sb.recv_buffers() for sb in ranks]
+    for step in range(3):
+        pushes = [vrt.make_push(vrt.CameraController(position=(24.0 + f + 3.0 * step, 25.0, -40.0 + 2.0 * f)), (48, 48, 48), res) for f in range(F)]
+        ref = [g.color.clone() for g in alone.step(pushes)]
+        for s, sb in enumerate(ranks):
+            sb.render(pushes)
+            sent = sb.pack()
+            for d in range(N):
+                ranks[d].wait_finals()                           # what start_gather() does before the buffers are overwritten
+                recv[d][s * FB:(s + 1) * FB].copy_(sent[d * FB:(d + 1) * FB])
+        for d, sb in enumerate(ranks):
+            sb._work = Arrived()
+            finals = sb.finish()
+            assert sb._unpack_pending
+        torch.cuda.synchronize()
+        for d, sb in enumerate(ranks):
+            for j, f in enumerate(sb.owned_frames()):
+                assert (sb.finals[j] == ref[f]).all(), (step, d, f)

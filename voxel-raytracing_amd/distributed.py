@@ -235,10 +235,11 @@ class ShardedBatch:
                             collective."""
 
     def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False,
-                 assemble_on: str = "root", rotate: bool = None, direct: bool = True):
+                 assemble_on: str = "root", rotate: bool = None, direct: bool = True, side_unpack: bool = False):
         import torch
         self.stage, self.F = stage, int(n_frames)
         self.host_staged = bool(host_staged)       # collective through host memory (gloo rehearsal of the N > 1 path on one GPU)
+        self.side_unpack = bool(side_unpack) and not self.host_staged      # assemble received frames on a second stream
         self.rank, self.nranks, self.group = int(rank), int(nranks), group
         if assemble_on not in ("root", "owners"):
             raise ValueError("assemble_on must be 'root' or 'owners'")
@@ -346,12 +347,28 @@ class ShardedBatch:
                 self._root = (bufs, n, src, dst, shards)
         return self._root[0]
 
-    def assemble(self):
+    def assemble(self, ctx=None):
         """After the collective filled recv_buffers(): the received strips into self.finals (one launch per 64 (source, frame)
-        pairs).  Rank 0 in "root" mode, every rank in "owners" mode."""
+        pairs).  Rank 0 in "root" mode, every rank in "owners" mode.  ctx: another context (stream) to run it on."""
         _, n, src, dst, shards = self._root
-        _capi.check(_capi.lib().vrt_unpack_rows_batch(self.stage.engine.ctx, n, src, dst, self.W, self.H, 4, shards))
+        _capi.check(_capi.lib().vrt_unpack_rows_batch(ctx or self.stage.engine.ctx, n, src, dst, self.W, self.H, 4, shards))
         return self.finals
+
+    def _side_stream(self):
+        """A second stream with a context of its own for the unpack (side_unpack): the strided copy of a step's frames is
+        HBM work that fits under the next step's tracing, which is instruction-bound."""
+        if getattr(self, "_side", None) is None:
+            import torch
+            from .host import Engine
+            dev = self.stage.engine.torch_device
+            self._side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._side):
+                self._side_engine = Engine(self.stage.engine.device)      # binds its context to the current (= side) stream
+            self._side_engine.set_timing(False)
+            self._ev_arrived = torch.cuda.Event()
+            self._ev_unpacked = torch.cuda.Event()
+            self._unpack_pending = False
+        return self._side
 
     def _receives(self) -> bool:
         return self.owners or self.rank == 0
@@ -383,14 +400,31 @@ class ShardedBatch:
             self._work = self._collective(src, hb, True)
             self._host = (src, hb, bufs)
             return
+        if getattr(self, "_unpack_pending", False):              # the receive buffers are still being read by the side stream
+            import torch
+            torch.cuda.current_stream().wait_event(self._ev_unpacked)
+            self._unpack_pending = False
         self._work = self._collective(self.packed, bufs, True)
 
     def finish(self):
         """Make the launch stream wait for the collective in flight (if any) and assemble its frames on the receivers.
-        Returns self.finals there when a collective was completed, else None."""
+        Returns self.finals there when a collective was completed, else None.  With side_unpack the assembly runs on a second
+        stream (self.finals is complete once that stream is: torch.cuda.synchronize(), or self.wait_finals())."""
         w = getattr(self, "_work", None)
         if w is None:
             return None
+        if getattr(self, "side_unpack", False) and self._receives() and not getattr(self, "host_staged", False):
+            import torch
+            side = self._side_stream()
+            with torch.cuda.stream(side):
+                w.wait()                                         # the SIDE stream waits for the collective ...
+                self._ev_arrived.record()
+                self.assemble(self._side_engine.ctx)             # ... and unpacks while the launch stream traces on
+                self._ev_unpacked.record()
+            self._unpack_pending = True
+            torch.cuda.current_stream().wait_event(self._ev_arrived)     # the launch stream: that collective's send buffer is free
+            self._work = None
+            return self.finals
         w.wait()
         self._work = None
         if getattr(self, "host_staged", False) and self._receives():
@@ -401,6 +435,12 @@ class ShardedBatch:
                 for b, h in zip(bufs, hb):
                     b.copy_(h)
         return self.assemble() if self._receives() else None
+
+    def wait_finals(self):
+        """Make the current stream wait for a side-stream assembly in flight (side_unpack)."""
+        if getattr(self, "_unpack_pending", False):
+            import torch
+            torch.cuda.current_stream().wait_event(self._ev_unpacked)
 
     def step(self, pushes, overlap: bool = True):
         """One step.  overlap=True: this step's K1 is launched first and runs while the previous step's collective is still
