@@ -397,23 +397,45 @@ __device__ __forceinline__ uint32_t udiv_uniform(uint32_t n, uint32_t d, uint32_
 // through the constant address space -- the table is not written while the kernel runs, and only loads the compiler
 // knows to be invariant become scalar loads (a plain global pointer gives vector loads and the slot in VGPRs).
 typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+// n dwords starting at byte offset `off` of slot `frame` of the table, read through the constant address space
+template <int N> __device__ __forceinline__ void table_read(const GeomParams& P, uint32_t frame, size_t off, void* dst)
+{
+    const_u32_ptr w = (const_u32_ptr)((const char*)(P.table + frame) + off);
+    uint32_t tmp[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) tmp[i] = w[i];
+    __builtin_memcpy(dst, tmp, sizeof tmp);
+}
 template <bool TABLE> struct SlotOf;
 template <> struct SlotOf<false> {
-    typedef const FrameSlot& type;
-    static __device__ __forceinline__ const FrameSlot& get(const GeomParams& P, uint32_t frame) { return P.slot[frame]; }
-};
-template <> struct SlotOf<true> {
-    typedef const FrameSlot type;
-    static __device__ __forceinline__ FrameSlot get(const GeomParams& P, uint32_t frame)
+    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank)
     {
-        const_u32_ptr w = (const_u32_ptr)(P.table + frame);
-        uint32_t tmp[sizeof(FrameSlot) / 4];
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(FrameSlot) / 4); i++) tmp[i] = w[i];
-        FrameSlot S;
-        __builtin_memcpy(&S, tmp, sizeof S);
-        return S;
+        const FrameSlot& S = P.slot[frame];
+        g = S.rg;
+        cam_pos[0] = S.pc.cam_pos[0]; cam_pos[1] = S.pc.cam_pos[1]; cam_pos[2] = S.pc.cam_pos[2];
+        cam_right[0] = S.pc.cam_right[0]; cam_right[1] = S.pc.cam_right[1]; cam_right[2] = S.pc.cam_right[2];
+        shard_rank = S.shard_rank;
     }
+    static __device__ __forceinline__ vrt_frame planes(const GeomParams& P, uint32_t frame) { return P.slot[frame].fr; }
+    static __device__ __forceinline__ const vrt_push* push(const GeomParams& P, uint32_t frame) { return &P.slot[frame].pc; }
+};
+// The table form reads the pieces when they are needed, like the kernel-argument form does: a copy of the whole slot at the
+// top keeps the fourteen plane pointers in scalar registers through the traversal (82 + 6 SGPRs: one wave per SIMD less).
+template <> struct SlotOf<true> {
+    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank)
+    {
+        table_read<sizeof(RayGenConsts) / 4>(P, frame, offsetof(FrameSlot, rg), &g);
+        table_read<3>(P, frame, offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_pos), cam_pos);
+        table_read<3>(P, frame, offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_right), cam_right);
+        table_read<1>(P, frame, offsetof(FrameSlot, shard_rank), &shard_rank);
+    }
+    static __device__ __forceinline__ vrt_frame planes(const GeomParams& P, uint32_t frame)
+    {
+        vrt_frame f;
+        table_read<sizeof(vrt_frame) / 4>(P, frame, offsetof(FrameSlot, fr), &f);
+        return f;
+    }
+    static __device__ __forceinline__ const vrt_push* push(const GeomParams& P, uint32_t frame) { return &P.table[frame].pc; }
 };
 
 // workgroup -> frame of the launch and tile row within the frame's local rows (ty) and tile column (tx).  Frames of a
@@ -497,12 +519,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     int x0, y0, yp0, ty, tx;
     uint32_t frame;
     if (!block_to_tile(M, frame, ty, tx)) return;                        // uniform per workgroup
-    typename SlotOf<TABLE>::type S = SlotOf<TABLE>::get(P, frame);
     // ... and so does the frame's part of ray generation (camera, hoisted constants, strip assignment), in one batch
-    RayGenConsts g = S.rg;
-    float cpx = S.pc.cam_pos[0], cpy = S.pc.cam_pos[1], cpz = S.pc.cam_pos[2];
-    float crx = S.pc.cam_right[0], cry = S.pc.cam_right[1], crz = S.pc.cam_right[2];
-    int shard_rank = S.shard_rank;
+    RayGenConsts g;
+    float cam_pos[3], cam_right[3];
+    int shard_rank;
+    SlotOf<TABLE>::head(P, frame, g, cam_pos, cam_right, shard_rank);
+    float cpx = cam_pos[0], cpy = cam_pos[1], cpz = cam_pos[2];
+    float crx = cam_right[0], cry = cam_right[1], crz = cam_right[2];
     float rcp_w = P.rcp_w, rcp_h = P.rcp_h;
     int fast_div = P.fast_screen_div;
     asm volatile("" : "+s"(g.cd.x), "+s"(g.cd.y), "+s"(g.cd.z), "+s"(g.planeV.x), "+s"(g.planeV.y), "+s"(g.planeV.z), "+s"(g.jx), "+s"(g.jy),
@@ -532,7 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
     bool hit = h.material != 0;
 
-    const vrt_frame f = S.fr;                 // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store
+    const vrt_frame f = SlotOf<TABLE>::planes(P, frame);   // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store
     float depth = 0.0f;
     if (hit) depth = len3(mk3(h.pos.x - start.x, h.pos.y - start.y, h.pos.z - start.z));
     if (f.depth) f.depth[i] = depth;
@@ -562,7 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (MODE != 0) {
         f3 col;
         if (hit) {
-            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &S.pc; c.have_noise = false;
+            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame); c.have_noise = false;
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 col = color_main_ray<TRAV>(P, occ, c, h);
