@@ -6,7 +6,7 @@ algorithmic GB/s of the primary-ray DDA kernel against the MI355X HBM peak.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input: a batch of N x F frames (N = number of GPUs,
-F = --frames-per-gpu, default 8; consecutive camera poses of a dolly move), every frame cut into 16-row screen strips
+F = --frames-per-gpu, default 32; consecutive camera poses of the same 8-unit dolly move at every N and F), every frame cut into 16-row screen strips
 that are dealt round-robin to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch
 (vrt_render_geometry_batch / _slots: the next frame's tiles are dispatched while the previous frame drains), packs
 them, and ONE RCCL collective per step moves the strips to where the frames are assembled: frame block b (F frames) is
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
-    ap.add_argument("--frames-per-gpu", type=int, default=8, help="frames of the batch per GPU and step")
+    ap.add_argument("--frames-per-gpu", type=int, default=32, help="frames of the batch per GPU and step (<= 256 / GPUs for one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,9 +88,9 @@ def main():
     renderer = vrt.VoxelRenderer(engine, st, scene)
     pos0, yaw, pitch = vrt.synthetic.default_camera_for(NV, NV, NV)
     F = world * max(1, args.frames_per_gpu)                   # frames of a batch
-    # the same dolly move at every N (8 units of travel per step), sampled world times as finely: the rays per frame and
-    # their cost do not drift with N
-    poses = [np.array([pos0[0] + 1.5 * t, pos0[1] + 0.5 * t, pos0[2] + 2.0 * t], np.float32) for t in (f / world for f in range(F))]
+    # the same dolly move at every N and batch size (8 units of travel per step), sampled as finely as the batch has frames:
+    # the rays per frame and their cost do not drift with N
+    poses = [np.array([pos0[0] + 1.5 * t, pos0[1] + 0.5 * t, pos0[2] + 2.0 * t], np.float32) for t in (8.0 * f / F for f in range(F))]
     pushes = []
     for f in range(F):                                        # camera + push constants per pose, marshalled once
         renderer.camera.position = poses[f]
