@@ -2,7 +2,7 @@
 # Profile bench.py's K1 under rocprofv3 on the GPU box: one --kernel-trace --stats run and four --pmc passes
 # (FETCH_SIZE and WRITE_SIZE in passes of their own, as MI355X_MICROARCH.md prescribes; never combined with a trace).
 # Usage (through gpurun):  bash tools/profile_k1.sh
-# Afterwards, here:        python tools/pmc_summary.py <tag> "k_primary<4" 8 ; copy the stats csv into profiles/.
+# Afterwards, here:        python tools/pmc_summary.py <tag> "k_primary<4" 32 (frames per launch); copy the stats csv into profiles/.  Remove gpurun_out/pmc_* and gpurun_out/prof here first.
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/pmc_sq $R/gpurun_out/pmc_misc
