@@ -2,12 +2,12 @@
 """bench.py -- BASELINE metric: Mrays/s at 1080p on the treehouse scene (primary rays), plus the achieved
 algorithmic GB/s of the primary-ray DDA kernel against the MI355X HBM peak.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W                  (N > 1: starts the N ranks itself, one per GPU)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input: a batch of N x F frames (N = number of GPUs,
-F = --frames-per-gpu, default 32; consecutive camera poses of the same 8-unit dolly move at every N and F), every frame cut into 16-row screen strips
-that are dealt round-robin to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch
+F = --frames-per-gpu, default 32; consecutive camera poses of the same 8-unit dolly move at every N and F), every frame cut
+into screen strips that are dealt to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch
 (vrt_render_geometry_batch / _slots: the next frame's tiles are dispatched while the previous frame drains), packs
 them, and ONE RCCL collective per step moves the strips to where the frames are assembled: frame block b (F frames) is
 gathered to rank b, the N gathers issued as a single all-to-all so that every GPU receives over all of its xGMI links
@@ -19,14 +19,19 @@ collective and no copy.
 
 Workload = BASELINE.json configs[1]: treehouse stand-in (synthetic:treehouse(seed=2), 256^3 -- the real
 treehouse.vox is a git-LFS pointer in the reference checkout), 1920x1080, primary rays only.
+
+Besides the headline the JSON line carries (rank 0, N = 1, outside the timed region):
+  roofline.single_frame_launch   the same kernel with ONE frame per launch (the reference's call pattern, engine.cpp:81-92)
+  extra_configs                  BASELINE configs[2] (shadow ray + 1 and 2 denoiser passes) and the reference's default
+                                 workload (AO 4 x 64, shadow, <= 5 bounces, 2 passes; voxel_render_settings.hpp:21-35):
+                                 per-kernel ms, rays, DDA steps and the same algorithmic-byte accounting
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -34,13 +39,25 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured-achievable
 B_OUT = 37                     # bytes stored per pixel: the reference's 6-target G-buffer (geometry_stage.cpp:22-33)
+K3_BYTES_PASS0 = 8             # denoiser pass 0 (phi = +inf): colour in + colour out
+K3_BYTES_PASS = 28             # weighted pass: colour + normal + position in (4 + 4 + 16), colour out
+KERNEL_SOURCES = ("vrt_device.hip", "vrt_traverse.h", "vrt_spec.h", "vrt_internal.h", "vrt_api.hip", "Makefile")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def csrc_sha16():
+    """Identity of the kernel sources a PMC summary was collected on (tools/pmc_summary.py stores the same digest)."""
+    h = hashlib.sha256()
+    for n in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "voxel-raytracing_amd", "csrc", n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
@@ -51,22 +68,168 @@ def main():
     ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
     ap.add_argument("--frames-per-gpu", type=int, default=32, help="frames of the batch per GPU and step (<= 256 / GPUs for one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip single_frame_launch and extra_configs (profiling runs)")
+    return ap.parse_args()
 
+
+# ---- launcher: --gpus N without a launcher around us -------------------------------------------------------------------
+
+def spawn_ranks(n):
+    """Start n fresh copies of this command, one rank per GPU, BEFORE anything here touches torch or HIP; relay rank 0's
+    stdout (the JSON line); a rank that fails takes the others down and its exit code becomes ours."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        time.sleep(0.05)
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code if code > 0 else 1
+                log(f"bench.py: rank {r} exited with code {code}; stopping the other ranks")
+                break
+    for r in sorted(live):                                    # only after a failure: the exact children started above
+        procs[r].terminate()
+    for r in sorted(live):
+        try:
+            procs[r].wait(timeout=10)
+        except Exception:
+            procs[r].kill()
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    return rc
+
+
+def launcher_selftest(world, rank):
+    """VRT_BENCH_LAUNCH_ONLY=1: the ranks only rendezvous (gloo) and agree on a sum -- exercises spawn_ranks without a GPU
+    (tests/test_bench_launcher.py).  VRT_BENCH_FAIL_RANK=k makes rank k fail before the rendezvous."""
+    if os.environ.get("VRT_BENCH_FAIL_RANK", "") == str(rank):
+        sys.exit(3)
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        total = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        total = 1
+    if rank == 0:
+        print(json.dumps({"launcher_test": True, "n_gpus": world, "rank_sum": total}), flush=True)
+
+
+# ---- the measured legs ---------------------------------------------------------------------------------------------------
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def single_frame_launch(vrt, engine, renderer, pushes, W, H, S_frames, reps=3):
+    """K1 with ONE frame per launch: every launch alone on the device (synchronised before the next), timed by the
+    library's HIP events around the kernel; mean over the step's poses, best of `reps` sweeps."""
+    stage = renderer._geometryStage
+    launch = stage.prepare()
+    engine.set_timing(True)
+    best = None
+    for _ in range(reps):
+        tot = 0.0
+        for p in pushes:
+            launch(p)
+            engine.synchronize()
+            tot += engine.last_timings()["primary_ms"]
+        best = tot if best is None or tot < best else best
+    engine.set_timing(False)
+    ms = best / len(pushes)
+    b_alg = (sum(S_frames) / len(S_frames)) + W * H * B_OUT
+    return {"kernel_ms": round(ms, 5), "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "Mrays_per_s": round(W * H / (ms * 1e-3) / 1e6, 1),
+            "sample": f"{len(pushes)} poses of the step, one vrt_render_geometry call each, device idle between launches"}
+
+
+def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounces, iters, reps=9):
+    """One frame of a secondary-ray configuration at the bench resolution: kernel times from the library's HIP events
+    (median of `reps` isolated frames), ray / step counts from a second render with the count planes attached."""
+    st = vrt.VoxelRenderSettings(targetResolution=(W, H))
+    st.fsrSetttings.enable = False
+    st.occlusionSettings.numSamples = ao
+    st.traceSettings.shadows = bool(shadows)
+    st.traceSettings.maxReflections = bounces
+    st.denoiserSettings.enable = iters > 0
+    st.denoiserSettings.iterations = max(iters, 1)
+    geo = vrt.GeometryStage(engine, st, scene)
+    den = vrt.DenoiserStage(engine, st)
+    engine.set_timing(True)
+    tg, td = [], []
+    for _ in range(reps + 2):
+        gb = geo.record(push)
+        if iters > 0:
+            den.record(gb.color, gb.normal, gb.position)
+        engine.synchronize()
+        t = engine.last_timings()
+        tg.append(t["geometry_ms"]); td.append(t["denoise_ms"])
+    tg, td = tg[2:], td[2:]
+    dbg = vrt.GeometryStage(engine, st, scene, debug_planes=True).record(push)
+    engine.synchronize()
+    S = int(dbg.steps_total.to(torch.int64).sum().item())
+    rays = int(dbg.rays_total.to(torch.int64).sum().item())
+    engine.set_timing(False)
+    g_ms = median(tg)
+    b_geo = S + W * H * B_OUT
+    out = {"name": name, "ao_samples": ao, "shadows": int(bool(shadows)), "max_bounces": bounces, "denoiser_passes": iters,
+           "geometry_kernel": "k_primary<DF, megakernel>", "geometry_ms": round(g_ms, 5),
+           "rays_total": rays, "dda_steps_total": S, "Mrays_total_per_s": round(rays / (g_ms * 1e-3) / 1e6, 1),
+           "geometry_algorithmic_bytes": b_geo, "geometry_frac": round(b_geo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    if iters > 0:
+        d_ms = median(td)
+        b_den = W * H * (K3_BYTES_PASS0 + (iters - 1) * K3_BYTES_PASS)
+        out.update({"denoise_ms": round(d_ms, 5), "denoise_algorithmic_bytes": b_den,
+                    "denoise_frac": round(b_den / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "frame_ms": round(g_ms + d_ms, 5)})
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}; refusing to report a {world}-GPU run as {args.gpus}")
+        sys.exit(2)
+    if os.environ.get("VRT_BENCH_LAUNCH_ONLY") == "1":
+        return launcher_selftest(world, rank)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import voxel_raytracing_amd as vrt
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal of the N > 1 control flow on a box with ONE GPU: VRT_BENCH_BACKEND=gloo VRT_BENCH_DEVICE=0 makes every rank
     # use cuda:0 and sends the gather through host memory (numbers from such a run are not benchmark results)
     backend = os.environ.get("VRT_BENCH_BACKEND", "nccl")
     if "VRT_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["VRT_BENCH_DEVICE"])
-    if world != args.gpus:
-        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -171,6 +334,7 @@ def main():
             hit_frac.append(float((gb.hit_id != 0).float().mean().item()))
             if f == 0:
                 hit0 = gb.hit_id.cpu().numpy()
+        del stage, gb
         S_frame = S_frames[0]
         # a launch covers this rank's strips (1 / world of the rows) of frames_per_launch frames
         b_alg = (sum(S_frames) + frames_per_launch * W * H * B_OUT) / world
@@ -178,7 +342,8 @@ def main():
         tm = engine.last_timings()
         # HBM bytes per K1 launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
         # this same command; tools/pmc_summary.py -> profiles/*_k_primary_pmc.json).  Counters cannot be read from inside
-        # the process, so the committed summary is quoted, and only for the configuration it was collected on.
+        # the process, so the committed summary is quoted -- only for the configuration AND the kernel sources it was
+        # collected on (the summary carries the digest of csrc/; another digest means the number is stale and is dropped).
         traffic, traffic_src = None, None
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k_primary_pmc.json")))
@@ -187,15 +352,27 @@ def main():
                 pj = json.load(open(pm[-1]))
                 if int(pj.get("frames_per_launch", 1)) != frames_per_launch:
                     raise ValueError("PMC summary was collected at another batch size")
+                if pj.get("csrc_sha16") != csrc_sha16():
+                    raise ValueError(f"PMC summary {os.path.basename(pm[-1])} was collected on other kernel sources "
+                                     f"({pj.get('csrc_sha16')} != {csrc_sha16()})")
                 traffic = int(pj["hbm_bytes_per_launch"]["total_guide_rule"])
                 traffic_src = os.path.relpath(pm[-1], ROOT)
-            except Exception:
-                traffic = None
+            except Exception as e:
+                traffic, traffic_src = None, f"dropped: {e}"
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "k_primary", "kernel_ms": round(kern_ms, 5),
+                    "frac_is": "algorithmic bytes (SURVEY 8(d): 1 B per DDA step + 37 B per pixel) / kernel time / peak",
+                    "traffic_GBps": round(traffic / (kern_ms * 1e-3) / 1e9, 2) if traffic else None,
+                    "kernel": "k_primary", "kernel_ms": round(kern_ms, 5), "csrc_sha16": csrc_sha16(),
                     "frames_per_launch": frames_per_launch, "algorithmic_bytes_per_launch": int(b_alg),
                     "dda_steps_per_frame": S_frame, "steps_per_ray": round(S_frame / (W * H), 2)}
+        extra = None
+        if world == 1 and not args.no_extra_configs:
+            roofline["single_frame_launch"] = single_frame_launch(vrt, engine, renderer, pushes[:frames_per_launch], W, H, S_frames)
+            extra = [extra_config(vrt, torch, engine, scene, pushes[0], W, H, *c) for c in (
+                ("configs[2]: primary + shadow ray, 1 denoiser pass", 0, True, 0, 1),
+                ("configs[2]: primary + shadow ray, 2 denoiser passes", 0, True, 0, 2),
+                ("reference defaults: AO 4 x 64 steps, shadow ray, <= 5 bounces, 2 denoiser passes", 4, True, 5, 2))]
         cpu = None
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is reported at N = 1 only
             from oracle import oracle                          # checker / CPU baseline only
@@ -209,7 +386,6 @@ def main():
             for f in sample:
                 exp = oracle.render(osn, pushes[f], oracle.params_from(st.to_c()), planes=["hit_id", "steps_primary"], nthreads=ncores)
                 if f == 0:
-                    cdt0 = time.perf_counter() - c0
                     same = bool((exp["hit_id"] == hit0).all()) and int(exp["steps_primary"].sum()) == S_frame
             cdt = time.perf_counter() - c0
             cpu = {"value": round(len(sample) * W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
@@ -228,12 +404,12 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"synthetic:treehouse(seed=2) {NV}^3 stand-in for treehouse.vox, {W}x{H}, primary rays only "
                                       f"(BASELINE configs[1]); {F} frame(s)/step ({F // world} per GPU, consecutive poses, one K1 launch per step), "
-                                      f"{sb.strip_rows}-row strips round-robin over {world} GPU(s)"
+                                      f"{sb.strip_rows}-row strips over {world} GPU(s)"
                                       + ((", one RCCL all-to-all/step (frame block b assembled on rank b), strip assignment rotated per block"
                                           if sb.owners else ", one RCCL gather/step to rank 0") if world > 1 else ""),
                           "traversal": args.traversal, "frames_per_step": F, "assembled_frames_match_single_gpu": assembled_ok, "hit_fraction": round(hit_frac[0], 4), "bytes_out_per_px": B_OUT,
                           "device": engine.device_info()[0]},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extra}
         log(f"timings of last call: {tm}")
     if world > 1:
         dist.barrier()

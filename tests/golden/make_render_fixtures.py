@@ -66,9 +66,31 @@ def quantisation():
     np.savez_compressed(os.path.join(HERE, "render_numeric.npz"), x=x, unorm8=un, snorm8=sn, atan2=at, asin=asn, exp=ex)
 
 
+def config1_inputs():
+    """BASELINE configs[0] at its stated size (SURVEY 8(d) "Config 1"): floating_cubes(N=128, seed=1), 256x256, primary rays
+    only, the reference default camera scaled to the volume: (N/2, N/2, -0.8 N), yaw 90, pitch 0."""
+    N = 128
+    vol = vrt.synthetic.floating_cubes(N, seed=1)
+    pal = vrt.synthetic.default_palette()
+    st = vrt.VoxelRenderSettings.primary_only((256, 256))
+    pos, yaw, pitch = vrt.synthetic.default_camera_for(N, N, N)
+    push = vrt.make_push(vrt.CameraController(position=pos, yaw=yaw, pitch=pitch), (N, N, N), (256, 256))
+    return vol, pal, st, push
+
+
+def config1():
+    vol, pal, st, push = config1_inputs()
+    out = oracle.render(oracle.OracleScene(vol, pal), push, oracle.params_from(st.to_c()), nthreads=8)
+    keep = {k: out[k] for k in ("hit_id", "hit_mask", "hit_voxel", "steps_primary", "color8", "depth", "normal8")}
+    keep["crc_hit_id"] = np.array([zlib.crc32(out["hit_id"].tobytes())], np.uint32)
+    keep["step_sum"] = np.array([int(out["steps_primary"].astype(np.int64).sum())], np.int64)
+    np.savez_compressed(os.path.join(HERE, "render_config1.npz"), **keep)
+    return keep
+
+
 if __name__ == "__main__":
     oracle.build()
-    cubes64(); denoise16(); quantisation()
+    cubes64(); denoise16(); quantisation(); config1()
     for f in sorted(os.listdir(HERE)):
         if f.startswith("render_"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

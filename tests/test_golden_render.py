@@ -88,3 +88,42 @@ def test_hip_reproduces_golden_denoise(vrt, engine):
             out = vrt.DenoiserStage(engine, st).record(c, n, p)
             engine.synchronize()
             assert (out.cpu().numpy() == g[f"out_mode{mode}_iter{it}"]).all(), (mode, it)
+
+
+# ---- BASELINE configs[0] at its stated workload: floating_cubes 128^3 @ 256x256, primary rays only ----------------------
+
+C1_PLANES = ["hit_id", "hit_mask", "hit_voxel", "steps_primary", "color8", "depth", "normal8"]
+
+
+def _config1_inputs():
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_render_fixtures import config1_inputs
+    return config1_inputs()
+
+
+def test_oracle_reproduces_config1(vrt, oracle):
+    g = np.load(os.path.join(GOLD, "render_config1.npz"))
+    vol, pal, st, push = _config1_inputs()
+    out = oracle.render(oracle.OracleScene(vol, pal), push, oracle.params_from(st.to_c()), planes=C1_PLANES, nthreads=8)
+    assert not compare_planes(out, g, C1_PLANES)
+    assert zlib.crc32(out["hit_id"].tobytes()) == int(g["crc_hit_id"][0])
+    assert int(out["steps_primary"].astype(np.int64).sum()) == int(g["step_sum"][0])
+    assert 0.1 < (g["hit_id"] != 0).mean() < 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trav", ["DF", "DENSE", "BITMASK", "JUMP", "DFJ"])
+def test_hip_reproduces_config1(vrt, engine, trav):
+    g = np.load(os.path.join(GOLD, "render_config1.npz"))
+    vol, pal, st, push = _config1_inputs()
+    st.traceSettings.traversal = getattr(vrt, "TRAVERSAL_" + trav)
+    sc = vrt.VoxelScene.from_dense(engine, vol, pal)
+    gb = vrt.GeometryStage(engine, st, sc, debug_planes=True).record(push)
+    engine.synchronize()
+    out = gb.numpy()
+    names = C1_PLANES if trav not in ("JUMP", "DFJ") else [p for p in C1_PLANES if not p.startswith("steps_")]
+    assert not compare_planes(out, g, names)
+    assert zlib.crc32(out["hit_id"].tobytes()) == int(g["crc_hit_id"][0])
+    if trav not in ("JUMP", "DFJ"):
+        assert int(out["steps_primary"].astype(np.int64).sum()) == int(g["step_sum"][0])

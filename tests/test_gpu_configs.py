@@ -1,4 +1,4 @@
-"""BASELINE configs 4 and 5 (and the maximum-size paths) as parity cases: bands of rows against the oracle, the whole
+"""BASELINE configs 3, 4 and 5 at their stated workloads (and the maximum-size paths) as parity cases: bands of rows against the oracle, the whole
 frame through properties that do not depend on its size -- every traversal mode must give the same planes, the sharded
 frame must equal the unsharded one."""
 import numpy as np
@@ -17,10 +17,70 @@ def _check_band(vrt, oracle, gb_np, osn, push, st, r0, r1, names):
     return compare_planes(got, exp, names)
 
 
-def test_config4_mandelbulb_4k_bounces(vrt, oracle, engine):
-    """Config 4: escape-time Mandelbulb, 3840x2160, max_bounces = 2, ids 200..255 metallic (0.8)."""
-    N = 160                                              # the 512^3 original differs only in scale; built in seconds
-    vol = vrt.synthetic.mandelbulb(N)
+@pytest.fixture(scope="module")
+def mandelbulb512(vrt):
+    """synthetic:mandelbulb(N=512, power=8, iters=8): ~10 s on 8 threads, generated once per session."""
+    return vrt.synthetic.mandelbulb(512)
+
+
+def test_config3_treehouse_1080p_shadow_denoise(vrt, oracle, engine):
+    """BASELINE configs[2] at its stated workload: treehouse 256^3, 1920x1080, primary + shadow ray (ao_samples = 0,
+    max_bounces = 0), denoiser iterations 1 and 2.  Whole frame: every traversal mode gives the same G-buffer and the same
+    denoised image; bands of rows: G-buffer and denoised rows against the oracle."""
+    vol = vrt.synthetic.treehouse(256, seed=2)
+    pal = metallic_palette(vrt)
+    sky, noise = vrt.synthetic.sky_gradient(512, 256), vrt.synthetic.blue_noise_standin(512)
+    sc = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
+    osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
+    res = (1920, 1080)
+    st = vrt.VoxelRenderSettings(targetResolution=res)
+    st.fsrSetttings.enable = False
+    st.occlusionSettings.numSamples = 0
+    st.traceSettings.maxReflections = 0
+    pos, yaw, pitch = vrt.synthetic.default_camera_for(256, 256, 256)
+    push = vrt.make_push(vrt.CameraController(position=pos, yaw=yaw, pitch=pitch), (256, 256, 256), res)
+    names = GB + ["hit_id", "rays_total"]
+    frames, den = {}, {}
+    for trav in ("DF", "DENSE", "BITMASK", "JUMP", "DFJ"):
+        st.traceSettings.traversal = getattr(vrt, "TRAVERSAL_" + trav)
+        gb = vrt.GeometryStage(engine, st, sc, debug_planes=True).record(push)
+        for it in (1, 2):
+            st.denoiserSettings.iterations = it
+            den[trav, it] = vrt.DenoiserStage(engine, st).record(gb.color, gb.normal, gb.position).cpu().numpy()
+        engine.synchronize()
+        frames[trav] = gb.numpy()
+    g = frames["DF"]
+    for trav in ("DENSE", "BITMASK", "JUMP", "DFJ"):
+        assert not compare_planes(frames[trav], g, names), trav
+        assert (den[trav, 1] == den["DF", 1]).all() and (den[trav, 2] == den["DF", 2]).all(), trav
+    hit = g["hit_id"] != 0
+    assert 0.15 < hit.mean() < 0.5 and int(g["rays_total"].max()) == 2 and (g["rays_total"][~hit] == 1).all()   # one shadow ray per hit
+    assert (den["DF", 1] != g["color8"]).any() and (den["DF", 2] != den["DF", 1]).any()
+    # split kernels (K1 -> records -> K2) give the same frame at full size
+    st.traceSettings.traversal = vrt.TRAVERSAL_DF
+    st.traceSettings.splitKernels = True
+    gs = vrt.GeometryStage(engine, st, sc, debug_planes=True).record(push)
+    engine.synchronize()
+    assert not compare_planes(gs.numpy(), g, names)
+    st.traceSettings.splitKernels = False
+    # oracle: G-buffer bands, and the denoised rows of each band (the filter reaches 1 + 3 rows: the oracle denoises the
+    # band plus that halo, cropped frames clamp at the crop's edge, so only rows with their full halo inside are compared)
+    halo = 4
+    for r0, r1 in ((0, 8), (536, 548), (1072, 1080)):
+        a, b = max(0, r0 - halo), min(res[1], r1 + halo)
+        exp = oracle.render_band(osn, push, oracle.params_from(st.to_c()), a, b, planes=names, nthreads=8)
+        assert not compare_planes({n: g[n][a:b] for n in names}, exp, names), (r0, r1)
+        for it in (1, 2):
+            od = oracle.denoise(exp["color8"], exp["normal8"], exp["position"], iterations=it)
+            assert (od[r0 - a:r1 - a] == den["DF", it][r0:r1]).all(), (r0, r1, it)
+    sc.destroy()
+
+
+def test_config4_mandelbulb512_4k_bounces(vrt, oracle, engine, mandelbulb512):
+    """BASELINE configs[3] at its stated workload: synthetic:mandelbulb(N=512), 3840x2160, max_bounces = 2, ids 200..255
+    metallic (0.8); AO 4 and the shadow ray stay at the reference defaults."""
+    N = 512
+    vol = mandelbulb512
     pal = metallic_palette(vrt)
     sky, noise = vrt.synthetic.sky_gradient(256, 128), vrt.synthetic.blue_noise_standin(128)
     sc = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
@@ -43,6 +103,20 @@ def test_config4_mandelbulb_4k_bounces(vrt, oracle, engine):
     assert (g["hit_id"] >= 200).mean() > 0.02 and (g["rays_total"] > 6).any()          # metallic hits and their bounces
     for r0 in (0, 1072, 2152):                                                         # top, middle, bottom bands of 8 rows
         assert not _check_band(vrt, oracle, g, osn, push, st, r0, r0 + 8, names)
+    # the sharded frame (8 simulated ranks, 16-row strips: the layout of the 8-GPU run) equals the unsharded one
+    st.traceSettings.traversal = vrt.TRAVERSAL_DF
+    stage = vrt.GeometryStage(engine, st, sc)
+    merged = {n: np.zeros_like(g[n]) for n in GB}
+    rows = np.arange(res[1])
+    for rank in range(8):
+        part = stage.record(push, vrt.make_shard(rank, 8, 16))
+        engine.synchronize()
+        pn = part.numpy()
+        own = ((rows // 16) % 8) == rank
+        for n in GB:
+            merged[n][own] = pn[n][own]
+    assert not compare_planes(merged, g, GB)
+    sc.destroy()
 
 
 def test_config5_sparse_bricks_long_budget(vrt, oracle, engine):

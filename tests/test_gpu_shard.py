@@ -47,11 +47,17 @@ def test_sharded_trace_assembles_to_full_frame(vrt, engine, nranks, strip_rows):
     assert (final == full).all()
 
 
-@pytest.mark.parametrize("nranks,strip_rows,iters", [(2, 16, 2), (3, 16, 2), (4, 32, 3)])
-def test_sharded_denoise_with_halo(vrt, engine, nranks, strip_rows, iters):
+# (stepWidth, iterations) beyond the default: extents of 2 and 6 rows put rows -2, -1 of rank 0's top strip in one 4-row
+# block with frame rows 0 and 1 (the block's origin must come from its first EXISTING row); stepWidth 0 keeps every
+# pass at a reach of 1; 2.5 takes the untiled bilinear kernel
+@pytest.mark.parametrize("nranks,strip_rows,iters,step_width", [(2, 16, 2, 2.0), (3, 16, 2, 2.0), (4, 32, 3, 2.0),
+                                                                (2, 16, 2, 1.0), (3, 16, 2, 1.0), (2, 16, 2, 5.0), (3, 16, 2, 5.0),
+                                                                (2, 16, 3, 0.0), (3, 16, 3, 1.0), (2, 16, 2, 2.5)])
+def test_sharded_denoise_with_halo(vrt, engine, nranks, strip_rows, iters, step_width):
     res = (96, 130)
     sc, st = _setup(vrt, engine, res, True)
     st.denoiserSettings.iterations = iters
+    st.denoiserSettings.stepWidth = step_width
     r = vrt.VoxelRenderer(engine, st, sc)
     r.camera.position = np.array([24.3, 24.2, -40.0], np.float32)
     full = r.render().clone(); engine.synchronize()
@@ -60,7 +66,7 @@ def test_sharded_denoise_with_halo(vrt, engine, nranks, strip_rows, iters):
     lib, ctx = vrt.lib(), engine.ctx
     ds = st.denoiser_to_c()
     halo = lib.vrt_denoise_halo_rows(C.byref(ds))
-    assert halo == sum(2 * i + 1 for i in range(iters))
+    assert halo == sum(int(np.ceil(i * step_width + 1)) for i in range(iters))
     # every rank traces its strips into its own G-buffer
     gbs = []
     for rank in range(nranks):

@@ -122,6 +122,7 @@ int vrt_ctx_set_stream(vrt_ctx* c, void* hip_stream)
     c->stream = (hipStream_t)hip_stream;      // NULL is a valid handle: the HIP null (legacy default) stream
     c->own_stream = false;
     c->have_geo = c->have_den = false;
+    c->checked_ptrs[0] = c->checked_ptrs[1] = 0;
     return VRT_OK;
 }
 
@@ -164,6 +165,7 @@ int vrt_device_free(vrt_ctx* c, void* p)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (p) HIPCHK(hipFree(p));
+    c->checked_ptrs[0] = c->checked_ptrs[1] = 0;     // a freed address may come back as something else: verify again
     return VRT_OK;
 }
 

@@ -868,8 +868,21 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
     const int x0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
     // rows of one block are consecutive frame rows (checked by the launcher); a single rank owns every row in order
     const bool whole = P.sh.nranks == 1 && P.extend == 0;
-    const int y0 = whole ? (r0 < P.H ? r0 : -1) : strip_row(P.sh, P.extend, r0, P.H);
-    if (y0 < 0) return;
+    // Sharded: the four rows of a block lie in one extended strip (per % 4 == 0), but the strip's first `extend` rows
+    // do not exist above the top of the frame (and its last ones may not below the bottom), so the block's frame row
+    // is taken from its first row that exists -- not from row r0, which for extend % 4 == 2 is missing while r0 + 2
+    // and r0 + 3 are frame rows 0 and 1.  y0 may be negative; the staging clamps and the row test below masks.
+    int y0 = -1;
+    bool any_row = false;
+    if (whole) { y0 = r0; any_row = r0 < P.H; }
+    else {
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const int yk = strip_row(P.sh, P.extend, r0 + k, P.H);
+            if (yk >= 0) { y0 = yk - k; any_row = true; }
+        }
+    }
+    if (!any_row) return;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     // staging: texel t = threadIdx.x + 256 k of the haloed tile, k = 0, 1, ... -- every thread gets the same number of
     // texels (+-1); (cx, cy) = (t % RW, t / RW) is kept without divisions: RW is 66..74, so threadIdx.x / RW is 0..3
@@ -897,8 +910,8 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
     }
     __syncthreads();
     const int px = x0 + lx, py = y0 + ly;
-    if (px >= P.W || py >= P.H) return;
-    if (!whole && strip_row(P.sh, P.extend, r0 + ly, P.H) != py) return;   // past the end of the strip / frame
+    if (px >= P.W || py < 0 || py >= P.H) return;
+    if (!whole && strip_row(P.sh, P.extend, r0 + ly, P.H) != py) return;   // above / past the end of the strip or frame
 
     constexpr int ntaps = SHIPPED ? 3 : 9;
     const float sw = P.step_width, sw2 = sw * sw;

@@ -19,8 +19,12 @@ from . import _capi
 
 
 def default_strip_rows(H: int, nranks: int) -> int:
-    """16-row strips (one tile row) unless that leaves a rank without work."""
-    return 16
+    """Rows per interleaved strip: a multiple of 16 (the C-ABI's granule), as large as still leaves every rank at least
+    four strips to balance sky against geometry with, at most 64 (1080 rows: 64 at N = 2 and 4, 32 at N = 8; a frame too
+    short for that gets 16-row strips, and then a rank may own fewer than four -- or none)."""
+    if nranks <= 1:
+        return 16
+    return int(min(64, max(16, H // (4 * nranks) // 16 * 16)))
 
 
 def band_strip_rows(H: int, nranks: int) -> int:

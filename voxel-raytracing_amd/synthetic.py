@@ -158,11 +158,13 @@ def treehouse(N: int = 256, seed: int = 2) -> np.ndarray:
     return v
 
 
-def mandelbulb(N: int = 128, power: float = 8.0, iters: int = 8, slab: int = 16) -> np.ndarray:
-    """Config 4 stand-in for mandlebulb.vox: escape-time Mandelbulb; id by escape iteration, interior 200+."""
+def mandelbulb(N: int = 128, power: float = 8.0, iters: int = 8, slab: int = 16, workers: int = 8) -> np.ndarray:
+    """Config 4 stand-in for mandlebulb.vox: escape-time Mandelbulb; id by escape iteration, interior 200+.
+    Slabs of `slab` z-layers are independent and are computed by `workers` threads (numpy releases the GIL)."""
     v = np.zeros((N, N, N), dtype=np.uint8)
     lin = (np.arange(N, dtype=np.float32) + 0.5) / N * 2.4 - 1.2
-    for z0 in range(0, N, slab):
+
+    def one(z0):
         zz, yy, xx = np.meshgrid(lin[z0:z0 + slab], lin, lin, indexing="ij")
         cx, cy, cz = xx, yy, zz
         px, py, pz = cx.copy(), cy.copy(), cz.copy()
@@ -186,6 +188,15 @@ def mandelbulb(N: int = 128, power: float = 8.0, iters: int = 8, slab: int = 16)
         near = (~inside) & (esc >= iters - 1)                              # thin shell of late escapers
         ids[near] = (20 + esc[near]).astype(np.uint8)
         v[z0:z0 + slab] = ids
+
+    starts = list(range(0, N, slab))
+    if workers > 1 and len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(workers)) as ex:
+            list(ex.map(one, starts))
+    else:
+        for z0 in starts:
+            one(z0)
     return v
 
 
