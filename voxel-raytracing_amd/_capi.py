@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvrt_hip.so")
+# VRT_LIB: another build of the SAME library (development variants: `make -C csrc variant NAME=x EXTRA=-D...` writes
+# csrc/libvrt_hip_x.so, e.g. with the traversal counters compiled in); still HIP only, still no CPU fallback
+LIB_PATH = os.environ.get("VRT_LIB") or os.path.join(_HERE, "csrc", "libvrt_hip.so")
 
 VRT_OK = 0
 ERR_NAMES = {1: "VRT_ERR_INVALID", 2: "VRT_ERR_IO", 3: "VRT_ERR_PARSE", 4: "VRT_ERR_NO_INSTANCE",

@@ -265,13 +265,22 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     SCHK(hipMalloc((void**)&s->occ2, n2pad * 8));
     SCHK(hipMalloc((void**)&s->occ3, n3pad * 8));
     SCHK(hipMalloc((void**)&s->palette, 256 * sizeof(vrt_material)));
-    SCHK(hipMalloc((void**)&s->df, 8 * ndf));
-    SCHK(hipMemsetAsync(s->df, 0, 8 * ndf, c->stream));
+    // eight clearance fields, and -- while 32-bit offsets reach all of it -- a ninth field with the voxel ids in the same
+    // layout plus one byte 0xFF behind it (trace_df_fast)
+    {
+        const bool fast = 9ull * ndf + 256ull <= 0xFFFFFFFFull && ((uint64_t)W + 2u) * ((uint64_t)H + 2u) < (1ull << 23);
+        const size_t bytes = fast ? 9 * ndf + 256 : 8 * ndf;
+        SCHK(hipMalloc((void**)&s->df, bytes));
+        SCHK(hipMemsetAsync(s->df, 0, bytes, c->stream));
+        if (fast) SCHK(hipMemsetAsync(s->df + 9 * ndf, 0xFF, 1, c->stream));
+        d.df_fast = fast ? 1u : 0u;
+    }
     SCHK(hipMemsetAsync(s->occ2, 0, n2pad * 8, c->stream));
     SCHK(hipMemsetAsync(s->occ3, 0, n3pad * 8, c->stream));
     SCHK(hipMemcpyAsync(s->vox, voxels, nvox, hipMemcpyHostToDevice, c->stream));
     SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_build_pyramid(s->vox, d.W, d.H, d.D, s->occ1, s->occ2, s->occ3, c->stream));
+    if (d.df_fast) SCHK(launch_pad_vox(s->vox, d.W, d.H, d.D, s->df + 8 * ndf, c->stream));
     {
         uint8_t *tmp0 = nullptr, *tmp1 = nullptr;               // ping-pong buffers of the 3-pass transforms
         SCHK(hipMalloc((void**)&tmp0, nvox));
@@ -601,12 +610,37 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     p.wgs_per_frame = (uint32_t)p.chunk * 8u;
     p.xcd_turn = (n > 1 && p.tiles_y_local > 0 && ceil_div(p.tiles_y_local, 8) * 8 * 100 > p.tiles_y_local * 103) ? 1 : 0;
     p.wgs_per_frame_rcp = p.wgs_per_frame ? (uint32_t)(0x100000000ull / (uint64_t)p.wgs_per_frame) : 0u;
+    // launches of 8 or more unsharded frames: one screen region per XCD and frame, rotating (block_to_tile, xcd_turn == 2)
+    {
+        const char* e = getenv("VRT_XCD_REGIONS");                       // development switch: 0 = off
+        const bool want = !(e && e[0] == '0');
+        if (want && n >= 8 && p.sh.nranks == 1 && p.tile_h == 8 && p.tiles_x >= 4 && p.tiles_y_local >= 8) {
+            const uint32_t rw = ((uint32_t)p.tiles_x + 1u) / 2u, rh = ((uint32_t)p.tiles_y_local + 3u) / 4u;
+            p.xcd_turn = 2;
+            p.wgs_per_frame = rw * rh;
+            p.wgs_per_frame_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.wgs_per_frame);
+            p.tiles_y_rcp = (uint32_t)(0x100000000ull / (uint64_t)rw);
+        }
+    }
     p.tps = (uint32_t)(p.sh.strip_rows / p.tile_h);
     p.tiles_x_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tiles_x);
-    p.tiles_y_rcp = p.tiles_y_local ? (uint32_t)(0x100000000ull / (uint64_t)p.tiles_y_local) : 0u;
+    if (p.xcd_turn != 2) p.tiles_y_rcp = p.tiles_y_local ? (uint32_t)(0x100000000ull / (uint64_t)p.tiles_y_local) : 0u;
     p.tps_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tps);
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
+    // primary rays only, default traversal, every wave full, a budget the recovery of positions from sideDist is exact for:
+    // the hand-written look-up loop (vrt_traverse.h trace_df_fast)
+    {
+        const char* e = getenv("VRT_FAST_LOOP");                          // development switch: 0 = off
+        const bool want = !(e && e[0] == '0');
+        const bool df = st->traversal == VRT_TRAVERSAL_AUTO || st->traversal == VRT_TRAVERSAL_DF;
+        if (want && p.fused_shade == 1 && df && s->d.vol.df_fast && st->max_steps >= 1 && st->max_steps <= 1024 && p.tile_h == 8 &&
+            W % 8 == 0 && H % 8 == 0 && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u))) {
+            bool voxel_plane = false;                             // the fast loop keeps no mapPos: no hit_voxel plane
+            for (int f = 0; f < n; f++) voxel_plane = voxel_plane || frames[f].hit_voxel != nullptr;
+            if (!voxel_plane) p.fused_shade = 3;
+        }
+    }
     p.occ2_bytes = s->occ2_bytes; p.occ3_bytes = s->occ3_bytes;
     p.occ_in_lds = ((size_t)s->occ2_bytes + s->occ3_bytes <= 65536) ? 1 : 0;
     if (!p.fused_shade) {

@@ -134,6 +134,24 @@ hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df,
     return hipGetLastError();
 }
 
+// field 8 of the clearance allocation: the voxel ids in the fields' zero-bordered layout (trace_df_fast reads the id of a hit
+// at the index it already has); the border stays 0
+__global__ __launch_bounds__(256) void k_pad_vox(const uint8_t* __restrict__ vox, uint8_t* __restrict__ dst, int W, int H, int D)
+{
+    size_t n = (size_t)W * H * D;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x = (int)(i % (size_t)W), y = (int)((i / (size_t)W) % (size_t)H), z = (int)(i / ((size_t)W * H));
+    dst[(size_t)(x + 1) + ((size_t)(y + 1) + (size_t)(z + 1) * ((size_t)H + 2u)) * ((size_t)W + 2u)] = vox[i];
+}
+
+hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst, hipStream_t s)
+{
+    size_t n = (size_t)W * H * D;
+    hipLaunchKernelGGL(k_pad_vox, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, vox, dst, W, H, D);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // traversal
 // ---------------------------------------------------------------------------------------------
@@ -165,11 +183,12 @@ __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 }
 
 // traceRay, voxel_volume.frag:176-196
-template <int TRAV, class Occ, bool AHEAD = false>
+template <int TRAV, class Occ, bool AHEAD = false, bool FAST = false>
 __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 start, f3 dir,
                                           uint32_t maxSteps, RayHit& h, RayInt& r)
 {
-    trace_int<TRAV, decltype(occ.o2), AHEAD>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
+    if (FAST) { NoStats ns; trace_df_fast(s.vol, start, dir, maxSteps, r, ns); }
+    else trace_int<TRAV, decltype(occ.o2), AHEAD>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
     h.material = r.material;
     h.dir = dir;
     // values first, one assignment to h afterwards: stores to h from both sides of the branch were being merged into
@@ -453,6 +472,21 @@ __device__ __forceinline__ bool block_to_tile(const TileMap& M, uint32_t& frame,
 {
     uint32_t b = blockIdx.x, utx;
     frame = 0;
+    if (M.xcd_turn == 2) {
+        // xcd_turn == 2: per frame every XCD owns ONE of 8 screen regions (2 columns x 4 rows of tiles), and the assignment
+        // rotates from frame to frame (XCD x traces region (x + frame) % 8): an XCD's rays of one frame then walk one
+        // eighth of the volume in one or two direction octants -- a working set of clearance bytes that fits its 4 MiB L2
+        // instead of the whole 17 MB field -- while over 8 frames every XCD traces every region once, so sky and geometry
+        // regions balance.  (wgs_per_frame = workgroup slots per region, tiles_y_rcp = floor(2^32 / region width).)
+        const uint32_t rw = ((uint32_t)M.tiles_x + 1u) >> 1, rh = ((uint32_t)M.tiles_y_local + 3u) >> 2;
+        uint32_t within, uty;
+        frame = udiv_uniform(b >> 3, M.wgs_per_frame, M.wgs_per_frame_rcp, within);
+        uty = udiv_uniform(within, rw, M.tiles_y_rcp, utx);
+        const uint32_t region = ((b & 7u) + frame) & 7u;
+        tx = (int)(utx + (region & 1u) * rw);
+        ty = (int)(uty + (region >> 1) * rh);
+        return frame < (uint32_t)M.n_frames && uty < rh && tx < M.tiles_x && ty < M.tiles_y_local;
+    }
     if (M.xcd_turn) {
         uint32_t L = udiv_uniform(b >> 3, (uint32_t)M.tiles_x, M.tiles_x_rcp, utx) * 8u + (b & 7u), uty;
         frame = udiv_uniform(L, (uint32_t)M.tiles_y_local, M.tiles_y_rcp, uty);
@@ -502,7 +536,8 @@ template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomPara
 // K1: primary rays
 // ---------------------------------------------------------------------------------------------
 
-// MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;
+// MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;  3: MODE 1 with the hand-written
+//         look-up loop (trace_df_fast; the host checks its preconditions: every wave full, budget <= 1024, ninth field);
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
@@ -552,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     f3 start = mk3(cpx, cpy, cpz);
     f3 dir = primary_dir_fast(g, crx, cry, crz, rcp_w, rcp_h, fast_div, px, py);
     RayHit h; RayInt r;
-    trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
+    trace_ray<TRAV, OccT<kLds>, MODE == 1, MODE == 3>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
     bool hit = h.material != 0;
 
     const vrt_frame f = SlotOf<TABLE>::planes(P, frame);   // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store
@@ -586,7 +621,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         f3 col;
         if (hit) {
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame); c.have_noise = false;
-            if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
+            if (MODE == 1 || MODE == 3) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 col = color_main_ray<TRAV>(P, occ, c, h);
                 if (f.steps_total && !(P.st.flags & 3u)) f.steps_total[i] = r.fetches + c.fetches;
@@ -673,10 +708,15 @@ template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
     unsigned wgs = (unsigned)(p.chunk * 8) * (unsigned)p.n_frames;
-    if (p.xcd_turn) wgs = (unsigned)p.tiles_x * 8u * (unsigned)((p.tiles_y_local * p.n_frames + 7) / 8);
+    if (p.xcd_turn == 2) wgs = 8u * (unsigned)p.n_frames * p.wgs_per_frame;
+    else if (p.xcd_turn) wgs = (unsigned)p.tiles_x * 8u * (unsigned)((p.tiles_y_local * p.n_frames + 7) / 8);
     dim3 grid(wgs), block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
-    if (p.table) {               // the split form renders one frame per launch and never gets here
+    if (TRAV == VRT_TRAVERSAL_DF && p.fused_shade == 3) {
+        if (p.table) hipLaunchKernelGGL((k_primary<VRT_TRAVERSAL_DF, false, 3, true>), grid, block, lds, s, p);
+        else         hipLaunchKernelGGL((k_primary<VRT_TRAVERSAL_DF, false, 3, false>), grid, block, lds, s, p);
+    }
+    else if (p.table) {               // the split form renders one frame per launch and never gets here
         if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, true>), grid, block, lds, s, p);
         else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, true>), grid, block, lds, s, p);
         else return hipErrorInvalidValue;

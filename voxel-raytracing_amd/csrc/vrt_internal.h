@@ -122,7 +122,8 @@ struct GeomParams {
     uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)
     uint32_t*  hit_count;      // K1 -> K2: number of hit pixels (zeroed before K1)
     uint32_t*  hit_list;       // K1 -> K2: their pixel indices, in arrival order
-    int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled)
+    int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled); 3: the same with the hand-written
+                               // look-up loop; 2: megakernel; 0: split
     int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
     uint32_t   occ2_bytes, occ3_bytes;   // both multiples of 16
 };
@@ -163,6 +164,7 @@ struct BlitParams {
 hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_t* occ1, uint64_t* occ2,
                                 uint64_t* occ3, hipStream_t s);
 hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s);
+hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst, hipStream_t s);
 hipError_t launch_primary(const GeomParams& p, hipStream_t s);
 hipError_t launch_shade(const GeomParams& p, hipStream_t s);
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s);

@@ -54,6 +54,10 @@ struct VolumeView {
                              // empty cube that has this voxel as its corner and extends towards the octant's signs;
                              // outside the volume counts as solid)
     uint64_t        df_stride;  // bytes between octant fields
+    uint32_t        df_fast;    // 1: the allocation continues with a ninth field, the voxel ids in the same zero-bordered layout
+                                // (field 8), and one byte 0xFF at offset 9 * df_stride, and all of it is addressable with
+                                // 32-bit offsets (trace_df_fast)
+    uint32_t        df_pad_;
     int32_t W, H, D;
     int32_t n1x, n1y, n1z;
     int32_t n2x, n2y, n2z;
@@ -758,6 +762,220 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
     VRT_DF_COUNT(r.dbg0 = n_outer; r.dbg1 = n_long;)
 #undef VRT_DF_COUNT
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- DF, hand-written look-up loop (primary rays of the primary-only kernel) ----------------------------------------------
+// Same march, same results as trace_df_impl<true, ., true>; what differs is what it costs to get from one look-up to the
+// next.  Measured issue costs on gfx950 at 8 waves per SIMD (tools/ubench/issue_cost.hip; unit: one v_add_f32, about 3
+// cycles of a SIMD): two-source vector ops 0.85-1.0, v_min3 / compares into a scalar pair / v_cndmask with a scalar mask /
+// conversions / 24-bit mads about 1.5, a DPP step 1.2 (+0.4 for its s_nop), v_cmpx + v_add as a pair 1.7, scalar
+// instructions issued between vector ones almost nothing.  So the loop is written for few, cheap VECTOR instructions:
+//  * a finished lane does not leave EXEC: its deltas are zeroed (x + 0 = x: its sideDist stands still), its index points
+//    at a byte that holds 0xFF, so the byte it reads IS its vote -- no select, no "done" mask, no live mask: every
+//    iteration runs with EXEC = all lanes (the kernel guarantees full waves);
+//  * iterations are the EXEC-narrowing form (v_min3, then per axis v_cmpx + v_add under it: 6.9 units; the compare-
+//    select-add form without EXEC writes measured 10.0);
+//  * one compare (byte < 2) answers both "did a lane hit" and "is the run a single iteration" (half of all look-ups);
+//    the DPP minimum runs only when every live lane has two or more iterations to go;
+//  * where a ray stands is recovered from how far its sideDist has come since the START of the ray, n = rint(side * g + c)
+//    per axis (c = -side0 * g): no copies of sideDist per run, no mapPos; the voxel id at a hit is read from a copy of
+//    the volume in the fields' own layout at the same index.  |error of n| <= (n^2 + 3n) 2^-24 (n additions, each rounded to
+//    the running sum's ulp), far below 1/2 for the budgets this path accepts (maxSteps <= 1024: 0.063).  An axis the ray
+//    cannot step along has side = +inf and g = 0: the product is v_mul_legacy_f32's (0 * anything = 0; a NaN would
+//    convert to INT_MIN, tools/ubench/nan_cvt.hip).
+// Preconditions (checked by the host): v.df_fast, 1 <= maxSteps <= 1024, all 64 lanes of the wave active.
+// Hazards kept by hand inside the block (gfx950): a DPP source needs two wait states after a vector write, a DPP five
+// after a write of EXEC; a scalar pair written by a vector compare needs two before a vector instruction reads it as mask.
+__device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
+                                             float& x, float& y, float& z, float dx, float dy, float dz,
+                                             float gx, float gy, float gz, float cx, float cy, float cz,
+                                             uint32_t idx0, uint32_t voxoff, uint32_t& lmask, uint32_t& material, uint32_t& fetches,
+                                             uint64_t kx, uint64_t ky, uint64_t kz)
+{
+#define VRT_F_EITER                                              \
+        "s_mov_b64 exec, -1\n\t"                                  \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
+        "v_cmpx_eq_u32 v48, %[x]\n\t"                             \
+        "v_add_f32 %[x], %[x], %[dx]\n\t"                         \
+        "s_mov_b64 exec, -1\n\t"                                  \
+        "v_cmpx_eq_u32 v48, %[y]\n\t"                             \
+        "v_add_f32 %[y], %[y], %[dy]\n\t"                         \
+        "s_mov_b64 exec, -1\n\t"                                  \
+        "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
+        "v_add_f32 %[z], %[z], %[dz]\n\t"
+    // scalars of the block: s60 = i (iterations done by every live lane), s61 = kw, s62 = left / iterations still to do,
+    // s63 = 0xFF, s[66:67] = saved EXEC; vectors: v48..v50 temporaries, v52 = the byte read = the lane's vote,
+    // v53 = index of the byte to read next
+    asm volatile(
+        "s_mov_b32 s60, 0\n\t"
+        "s_movk_i32 s63, 0xff\n\t"
+        "v_mov_b32 v53, %[idx0]\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "10:\n\t"                                                   // ---- look-up: every lane's byte is here ----
+        "s_waitcnt vmcnt(0)\n\t"
+        "11:\n\t"
+        "v_cmp_gt_u32_e32 vcc, 2, v52\n\t"                          // 0 (solid / border) or 1 (single iteration) somewhere?
+        "s_cbranch_vccnz 15f\n\t"
+        "v_mov_b32 v48, v52\n\t"                                    // wave minimum of the votes: every live lane has >= 2
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v48, v48, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v48, v48, v48 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v48, v48, v48 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v48, v48, v48 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v48, v48, v48 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v48, v48, v48 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_sub_u32 s62, %[maxs], s60\n\t"                           // left >= 1
+        "s_nop 0\n\t"
+        "v_readlane_b32 s61, v48, 63\n\t"
+        "s_nop 1\n\t"
+        "s_cmp_eq_u32 s61, s63\n\t"
+        "s_cbranch_scc1 40f\n\t"                                    // nobody is live: done
+        "s_min_u32 s61, s61, s62\n\t"
+        "12:\n\t"                                                   // ---- a run of kw = s61 >= 1 iterations ----
+        "s_add_u32 s60, s60, s61\n\t"                               // i += kw
+        "s_sub_u32 s62, s61, 1\n\t"                                 // plain iterations before the one whose masks are kept
+        "s_cmp_eq_u32 s62, 0\n\t"
+        "s_cbranch_scc1 34f\n\t"
+        "s_bitcmp0_b32 s62, 0\n\t"
+        "s_cbranch_scc1 31f\n\t"
+        VRT_F_EITER
+        "31:\n\t"
+        "s_bitcmp0_b32 s62, 1\n\t"
+        "s_cbranch_scc1 32f\n\t"
+        VRT_F_EITER
+        VRT_F_EITER
+        "32:\n\t"
+        "s_lshr_b32 s62, s62, 2\n\t"                                // quads; SCC = (quads != 0)
+        "s_cbranch_scc0 34f\n\t"
+        "s_sub_u32 s62, s62, 1\n\t"
+        "33:\n\t"
+        VRT_F_EITER
+        VRT_F_EITER
+        VRT_F_EITER
+        VRT_F_EITER
+        "s_sub_u32 s62, s62, 1\n\t"                                 // SCC = borrow: that was the last quad
+        "s_cbranch_scc0 33b\n\t"
+        "34:\n\t"                                                   // the run's last iteration: its EXEC masks are the mask bits
+        "s_mov_b64 exec, -1\n\t"
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
+        "v_cmpx_eq_u32 v48, %[x]\n\t"
+        "s_mov_b64 %[kx], exec\n\t"
+        "v_add_f32 %[x], %[x], %[dx]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_cmpx_eq_u32 v48, %[y]\n\t"
+        "s_mov_b64 %[ky], exec\n\t"
+        "v_add_f32 %[y], %[y], %[dy]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_cmpx_eq_u32 v48, %[z]\n\t"
+        "s_mov_b64 %[kz], exec\n\t"
+        "v_add_f32 %[z], %[z], %[dz]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        // ---- where is every lane now?  request its next byte ----
+        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"                     // (legacy: inf * 0 = 0, an axis the ray cannot step along)
+        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t"
+        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t"
+        "v_add_f32 v48, v48, %[cx]\n\t"
+        "v_add_f32 v49, v49, %[cy]\n\t"
+        "v_add_f32 v50, v50, %[cz]\n\t"
+        "v_cvt_rpi_i32_f32 v48, v48\n\t"
+        "v_cvt_rpi_i32_f32 v49, v49\n\t"
+        "v_cvt_rpi_i32_f32 v50, v50\n\t"
+        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t"
+        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t"
+        "v_add_u32 v53, %[idx0], v48\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "s_cmp_lt_u32 s60, %[maxs]\n\t"
+        "s_cbranch_scc1 10b\n\t"
+        // ---- the budget is spent: the lanes that are still live (their start index is not the 0xFF byte's) stop here ----
+        "v_cmp_ne_u32_e32 vcc, %[sent], %[idx0]\n\t"
+        "s_and_saveexec_b64 s[66:67], vcc\n\t"
+        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t"
+        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t"
+        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t"
+        "v_or3_b32 %[lm], v48, v49, v50\n\t"
+        "v_mov_b32 %[fet], s60\n\t"
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "s_branch 40f\n\t"
+        "15:\n\t"                                                   // ---- some lane read 0 or 1 ----
+        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t"
+        "s_mov_b32 s61, 1\n\t"
+        "s_cbranch_vccz 12b\n\t"                                    // only 1s: a single-iteration run
+        "s_and_saveexec_b64 s[66:67], vcc\n\t"                      // lanes that read 0: a solid voxel, or the border
+        "v_add_u32 v48, v53, %[voxoff]\n\t"
+        "global_load_ubyte %[mat], v48, %[base]\n\t"                // the voxel id (0 in the border: the ray has left the volume)
+        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t"
+        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t"
+        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t"
+        "v_or3_b32 %[lm], v48, v49, v50\n\t"
+        "v_mov_b32 %[fet], s60\n\t"
+        "v_mov_b32 %[dx], 0\n\t"
+        "v_mov_b32 %[dy], 0\n\t"
+        "v_mov_b32 %[dz], 0\n\t"
+        "v_mov_b32 %[gx], 0\n\t"
+        "v_mov_b32 %[gy], 0\n\t"
+        "v_mov_b32 %[gz], 0\n\t"
+        "v_mov_b32 %[cx], 0\n\t"
+        "v_mov_b32 %[cy], 0\n\t"
+        "v_mov_b32 %[cz], 0\n\t"
+        "v_mov_b32 %[idx0], %[sent]\n\t"
+        "v_mov_b32 v53, %[sent]\n\t"
+        "v_mov_b32 v52, s63\n\t"
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "s_nop 4\n\t"                                               // EXEC written -> DPP: five wait states
+        "s_branch 11b\n\t"                                          // the other lanes' bytes are still to be looked at
+        "40:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
+          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
+          [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), [fet] "+v"(fetches),
+          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz)
+        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53",
+          "s60", "s61", "s62", "s63", "s66", "s67");
+#undef VRT_F_EITER
+}
+
+template <class STATS>
+__device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
+{
+    DdaState s;
+    dda_entry(v, start, dir, s);
+    if (wave_all(oob(v, s.mx, s.my, s.mz))) {
+        s.dx = s.dy = s.dz = 0.0f; s.sdx = s.sdy = s.sdz = 0.0f; s.sx = s.sy = s.sz = 0;
+        finish(s, 0u, s.mask, 0u, r);
+        return;
+    }
+    dda_rest(dir, s);
+    const bool done0 = oob(v, s.mx, s.my, s.mz);
+    const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
+    const uint32_t stride = (uint32_t)v.df_stride;
+    const uint32_t octoff = oct * stride, sentinel = 9u * stride;
+    const int pw = v.W + 2, pwh = pw * (v.H + 2);
+    const float kInf = u2f(0x7F800000u);
+    // a lane that never enters the volume is finished from the start: zero deltas, the 0xFF byte
+    float dx = done0 ? 0.0f : s.dx, dy = done0 ? 0.0f : s.dy, dz = done0 ? 0.0f : s.dz;
+    float gx = (!done0 && s.dx < kInf) ? dir.x : 0.0f, gy = (!done0 && s.dy < kInf) ? dir.y : 0.0f, gz = (!done0 && s.dz < kInf) ? dir.z : 0.0f;
+    float cx = gx != 0.0f ? -(s.sdx * gx) : 0.0f, cy = gy != 0.0f ? -(s.sdy * gy) : 0.0f, cz = gz != 0.0f ? -(s.sdz * gz) : 0.0f;
+    const uint32_t idx0 = done0 ? sentinel : octoff + (uint32_t)df_index(v, s.mx, s.my, s.mz);
+    const uint32_t voxoff = 8u * stride - octoff;
+    uint32_t lmask = s.mask, material = 0u, fetches = 0u;
+    const uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
+    float x = s.sdx, y = s.sdy, z = s.sdz;
+    df_fast_loop(v.df, maxSteps, pw, pwh, sentinel, x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz);
+    s.sdx = x; s.sdy = y; s.sdz = z;
+    finish(s, material, lmask, fetches + (material != 0u ? 1u : 0u), r);
+    (void)stats;
+}
+#elif defined(__HIPCC__)
+// host pass of a .hip file: device functions are parsed, never run
+template <class STATS>
+__device__ void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
+#endif
 
 template <class STATS, bool AHEAD = false>
 VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
