@@ -790,8 +790,25 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
                                              float& x, float& y, float& z, float dx, float dy, float dz,
                                              float gx, float gy, float gz, float cx, float cy, float cz,
                                              uint32_t idx0, uint32_t voxoff, uint32_t& lmask, uint32_t& material, uint32_t& fetches,
-                                             uint64_t kx, uint64_t ky, uint64_t kz)
+                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz)
 {
+    // the same iteration that also moves the index of the lane's voxel: one more vector instruction per axis under the
+    // EXEC mask that is there anyway -- cheaper than recovering the position afterwards for runs of up to four iterations
+    // (three quarters of all runs)
+#define VRT_F_EITER_IDX                                          \
+        "s_mov_b64 exec, -1\n\t"                                  \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
+        "v_cmpx_eq_u32 v48, %[x]\n\t"                             \
+        "v_add_f32 %[x], %[x], %[dx]\n\t"                         \
+        "v_add_u32 v53, v53, %[ix]\n\t"                           \
+        "s_mov_b64 exec, -1\n\t"                                  \
+        "v_cmpx_eq_u32 v48, %[y]\n\t"                             \
+        "v_add_f32 %[y], %[y], %[dy]\n\t"                         \
+        "v_add_u32 v53, v53, %[iy]\n\t"                           \
+        "s_mov_b64 exec, -1\n\t"                                  \
+        "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
+        "v_add_f32 %[z], %[z], %[dz]\n\t"                         \
+        "v_add_u32 v53, v53, %[iz]\n\t"
 #define VRT_F_EITER                                              \
         "s_mov_b64 exec, -1\n\t"                                  \
         "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
@@ -816,7 +833,9 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "11:\n\t"
         "v_cmp_gt_u32_e32 vcc, 2, v52\n\t"                          // 0 (solid / border) or 1 (single iteration) somewhere?
         "s_cbranch_vccnz 15f\n\t"
-        "v_mov_b32 v48, v52\n\t"                                    // wave minimum of the votes: every live lane has >= 2
+        "v_cmp_gt_u32_e32 vcc, 4, v52\n\t"                          // 2 or 3 somewhere (and nothing below)?
+        "s_cbranch_vccnz 16f\n\t"
+        "v_mov_b32 v48, v52\n\t"                                    // wave minimum of the votes: every live lane has >= 4
         "s_nop 1\n\t"
         "v_min_u32_dpp v48, v48, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
@@ -836,7 +855,9 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_cmp_eq_u32 s61, s63\n\t"
         "s_cbranch_scc1 40f\n\t"                                    // nobody is live: done
         "s_min_u32 s61, s61, s62\n\t"
-        "12:\n\t"                                                   // ---- a run of kw = s61 >= 1 iterations ----
+        "s_cmp_le_u32 s61, 4\n\t"
+        "s_cbranch_scc1 18f\n\t"
+        // ---- a run of kw = s61 >= 5 iterations: plain iterations, then the positions from the sideDist travelled ----
         "s_add_u32 s60, s60, s61\n\t"                               // i += kw
         "s_sub_u32 s62, s61, 1\n\t"                                 // plain iterations before the one whose masks are kept
         "s_cmp_eq_u32 s62, 0\n\t"
@@ -892,6 +913,7 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_cmp_lt_u32 s60, %[maxs]\n\t"
         "s_cbranch_scc1 10b\n\t"
         // ---- the budget is spent: the lanes that are still live (their start index is not the 0xFF byte's) stop here ----
+        "19:\n\t"
         "v_cmp_ne_u32_e32 vcc, %[sent], %[idx0]\n\t"
         "s_and_saveexec_b64 s[66:67], vcc\n\t"
         "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t"
@@ -901,10 +923,53 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "v_mov_b32 %[fet], s60\n\t"
         "s_mov_b64 exec, s[66:67]\n\t"
         "s_branch 40f\n\t"
+        "16:\n\t"                                                   // ---- the smallest vote is 2 or 3 ----
+        "v_cmp_eq_u32_e32 vcc, 2, v52\n\t"
+        "s_sub_u32 s62, %[maxs], s60\n\t"
+        "s_mov_b32 s61, 3\n\t"
+        "s_cbranch_vccz 17f\n\t"
+        "s_mov_b32 s61, 2\n\t"
+        "17:\n\t"
+        "s_min_u32 s61, s61, s62\n\t"
+        "18:\n\t"                                                   // ---- a run of kw = s61 in 1..4 iterations, index moved along ----
+        "s_add_u32 s60, s60, s61\n\t"
+        "s_cmp_eq_u32 s61, 1\n\t"
+        "s_cbranch_scc1 184f\n\t"
+        "s_cmp_eq_u32 s61, 2\n\t"
+        "s_cbranch_scc1 183f\n\t"
+        "s_cmp_eq_u32 s61, 3\n\t"
+        "s_cbranch_scc1 182f\n\t"
+        VRT_F_EITER_IDX
+        "182:\n\t"
+        VRT_F_EITER_IDX
+        "183:\n\t"
+        VRT_F_EITER_IDX
+        "184:\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
+        "v_cmpx_eq_u32 v48, %[x]\n\t"
+        "s_mov_b64 %[kx], exec\n\t"
+        "v_add_f32 %[x], %[x], %[dx]\n\t"
+        "v_add_u32 v53, v53, %[ix]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_cmpx_eq_u32 v48, %[y]\n\t"
+        "s_mov_b64 %[ky], exec\n\t"
+        "v_add_f32 %[y], %[y], %[dy]\n\t"
+        "v_add_u32 v53, v53, %[iy]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_cmpx_eq_u32 v48, %[z]\n\t"
+        "s_mov_b64 %[kz], exec\n\t"
+        "v_add_f32 %[z], %[z], %[dz]\n\t"
+        "v_add_u32 v53, v53, %[iz]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "s_cmp_lt_u32 s60, %[maxs]\n\t"
+        "s_cbranch_scc1 10b\n\t"
+        "s_branch 19b\n\t"
         "15:\n\t"                                                   // ---- some lane read 0 or 1 ----
         "v_cmp_eq_u32_e32 vcc, 0, v52\n\t"
         "s_mov_b32 s61, 1\n\t"
-        "s_cbranch_vccz 12b\n\t"                                    // only 1s: a single-iteration run
+        "s_cbranch_vccz 18b\n\t"                                    // only 1s: a single-iteration run
         "s_and_saveexec_b64 s[66:67], vcc\n\t"                      // lanes that read 0: a solid voxel, or the border
         "v_add_u32 v48, v53, %[voxoff]\n\t"
         "global_load_ubyte %[mat], v48, %[base]\n\t"                // the voxel id (0 in the border: the ray has left the volume)
@@ -922,6 +987,9 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "v_mov_b32 %[cx], 0\n\t"
         "v_mov_b32 %[cy], 0\n\t"
         "v_mov_b32 %[cz], 0\n\t"
+        "v_mov_b32 %[ix], 0\n\t"
+        "v_mov_b32 %[iy], 0\n\t"
+        "v_mov_b32 %[iz], 0\n\t"
         "v_mov_b32 %[idx0], %[sent]\n\t"
         "v_mov_b32 v53, %[sent]\n\t"
         "v_mov_b32 v52, s63\n\t"
@@ -933,11 +1001,12 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
           [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
           [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), [fet] "+v"(fetches),
-          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz)
+          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz)
         : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53",
           "s60", "s61", "s62", "s63", "s66", "s67");
 #undef VRT_F_EITER
+#undef VRT_F_EITER_IDX
 }
 
 template <class STATS>
@@ -966,7 +1035,10 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     uint32_t lmask = s.mask, material = 0u, fetches = 0u;
     const uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
     float x = s.sdx, y = s.sdy, z = s.sdz;
-    df_fast_loop(v.df, maxSteps, pw, pwh, sentinel, x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz);
+    // what one step along an axis adds to the index (0 for a lane that never enters the volume)
+    const int incx = done0 ? 0 : s.sx, incy = done0 ? 0 : s.sy * pw, incz = done0 ? 0 : s.sz * pwh;
+    df_fast_loop(v.df, maxSteps, pw, pwh, sentinel, x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
+                 incx, incy, incz);
     s.sdx = x; s.sdy = y; s.sdz = z;
     finish(s, material, lmask, fetches + (material != 0u ? 1u : 0u), r);
     (void)stats;
