@@ -1,7 +1,7 @@
-"""The hand-written look-up loop of the primary-only kernel (vrt_traverse.h trace_df_fast; chosen by the host when the frame
-is a whole number of 8x8 waves, the budget is <= 1024 and no hit_voxel plane is asked for) against the oracle and against
-the general kernel (VRT_FAST_LOOP=0): ties, axis-parallel rays, cameras inside the volume and on lattice points, rays
-that miss the box, budgets of 1 ... 1024, batches of frames, and a randomised sweep."""
+"""The hand-written look-up loop (vrt_traverse.h trace_df_fast; chosen by the host for AUTO / DF when the budgets are <= 1024
+and no hit_voxel plane is asked for) against the oracle and against the general loop (VRT_FAST_LOOP=0): primary rays and the
+secondary rays of the megakernel / split kernels (partly filled waves), ties, axis-parallel rays, cameras inside the volume
+and on lattice points, rays that miss the box, budgets of 1 ... 1024, ragged frame sizes, batches, and a randomised sweep."""
 import os
 
 import numpy as np
@@ -119,18 +119,39 @@ def test_fast_loop_batch_and_table(vrt, oracle, engine):
     sc.destroy()
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_fast_loop_secondary_rays(vrt, oracle, engine, split):
+    """AO 4 x 64, shadow ray, <= 5 bounces through the fast loop: hit lanes only are in EXEC while the secondary rays are
+    traced (the loop parks the other lanes), frame sizes that leave partly filled waves."""
+    vol = vrt.synthetic.floating_cubes(64, seed=21, count=150)
+    sky, noise = vrt.synthetic.sky_gradient(64, 32), vrt.synthetic.blue_noise_standin(64)
+    for res, pos in (((100, 60), None), ((61, 47), (30.2, 33.1, 20.4)), ((96, 64), (90.0, 70.0, -30.0))):
+        st = vrt.VoxelRenderSettings(targetResolution=res)
+        st.fsrSetttings.enable = False
+        st.traceSettings.splitKernels = split
+        push = camera_push(vrt, (64, 64, 64), res, pos=pos, yaw=90.0 if pos is None else 115.0, frame=11, jitter=(0.1, 0.2))
+        exp = _check(vrt, oracle, engine, vol, metallic_palette(vrt), st, push, sky=sky, noise=noise)
+        assert int(exp["rays_total"].max()) > 6
+
+
 def test_fast_loop_random_sweep(vrt, oracle, engine):
     rng = np.random.default_rng(2024)
-    for case in range(60):
+    for case in range(80):
         kind = int(rng.integers(0, 4))
         if kind == 0:   vol = vrt.synthetic.floating_cubes(int(rng.integers(16, 72)), seed=int(rng.integers(1, 1 << 30)), count=int(rng.integers(1, 200)))
         elif kind == 1: vol = vrt.synthetic.sparse_bricks(int(rng.choice([32, 48, 64])), int(rng.choice([2, 4, 8])), float(rng.uniform(0.005, 0.3)), seed=int(rng.integers(1, 1 << 30)))
         elif kind == 2: vol = vrt.synthetic.treehouse(int(rng.choice([32, 64])), seed=int(rng.integers(1, 1 << 30)))
         else:           vol = (rng.random((int(rng.integers(5, 70)), int(rng.integers(5, 70)), int(rng.integers(5, 70)))) < rng.uniform(0.0, 0.1)).astype(np.uint8) * np.uint8(rng.integers(1, 256))
         D, H, W = vol.shape
-        res = (8 * int(rng.integers(1, 20)), 8 * int(rng.integers(1, 15)))
+        res = (int(rng.integers(1, 160)), int(rng.integers(1, 120)))
         st = vrt.VoxelRenderSettings.primary_only(res)
         st.traceSettings.maxRaySteps = int(rng.choice([1, 7, 64, 512, 1000]))
+        if case % 2:                                              # secondary rays: AO / shadow / bounces, megakernel or split
+            st.occlusionSettings.numSamples = int(rng.integers(0, 5))
+            st.traceSettings.shadows = bool(rng.integers(0, 2))
+            st.traceSettings.maxReflections = int(rng.integers(0, 6))
+            st.traceSettings.aoSteps = int(rng.choice([1, 16, 64]))
+            st.traceSettings.splitKernels = bool(rng.integers(0, 4) == 0)
         mode = int(rng.integers(0, 4))
         if mode == 0:   pos = (W / 2 + rng.uniform(-1, 1), H / 2 + rng.uniform(-1, 1), -rng.uniform(0.2, 2.0) * D)
         elif mode == 1: pos = tuple(rng.uniform(0, 1, 3) * np.array([W, H, D]))
@@ -139,9 +160,10 @@ def test_fast_loop_random_sweep(vrt, oracle, engine):
         yaw = float(rng.choice([90.0, 0.0, 45.0, rng.uniform(0, 360)])); pitch = float(rng.choice([0.0, 45.0, -30.0, rng.uniform(-89, 89)]))
         push = vrt.make_push(vrt.CameraController(position=pos, yaw=yaw, pitch=pitch), (W, H, D), res, frame=int(rng.integers(0, 100)),
                              jitter=(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))))
-        sc = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt))
+        sky, noise = vrt.synthetic.sky_gradient(int(rng.choice([1, 7, 64])), int(rng.choice([1, 5, 32]))), vrt.synthetic.blue_noise_standin(int(rng.choice([1, 16, 64])))
+        sc = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt), sky=sky, noise=noise)
         fast = _render(vrt, engine, sc, st, push, True)
-        exp = oracle.render(oracle.OracleScene(vol, metallic_palette(vrt)), push, oracle.params_from(st.to_c()), planes=PLANES, nthreads=8)
+        exp = oracle.render(oracle.OracleScene(vol, metallic_palette(vrt), sky=sky, noise=noise), push, oracle.params_from(st.to_c()), planes=PLANES, nthreads=8)
         bad = compare_planes(fast, exp, PLANES)
         assert not bad, (case, kind, vol.shape, res, st.traceSettings.maxRaySteps, pos, yaw, pitch, bad[:2])
         sc.destroy()

@@ -67,6 +67,7 @@ struct vrt_scene {
     vrt_material* palette = nullptr;
     float* sky = nullptr;
     uint8_t* noise = nullptr;
+    float* sky_normals = nullptr;
     uint32_t occ2_bytes = 0, occ3_bytes = 0;
 };
 
@@ -209,6 +210,7 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->palette) hipFree(s->palette);
     if (s->sky) hipFree(s->sky);
     if (s->noise) hipFree(s->noise);
+    if (s->sky_normals) hipFree(s->sky_normals);
     delete s;
 }
 
@@ -223,6 +225,11 @@ int vrt_scene_set_sky(vrt_ctx* c, vrt_scene* s, const float* rgba, uint32_t w, u
     HIPCHK(hipMemcpy(d, rgba, bytes, hipMemcpyHostToDevice));
     if (s->sky) hipFree(s->sky);
     s->sky = d; s->d.sky = d; s->d.sky_w = w; s->d.sky_h = h;
+    // skyColor of the normals a hit can have (calcAmbient's sky tint, frag:224): 64 x float4, by the shading code itself
+    if (!s->sky_normals) HIPCHK(hipMalloc((void**)&s->sky_normals, 64 * 4 * sizeof(float)));
+    s->d.sky_normals = s->sky_normals;
+    HIPCHK(launch_sky_normals(s->d, s->sky_normals, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return VRT_OK;
 }
 
@@ -585,6 +592,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     }
     FrameSlot* slots = p.slot;
     int tab = -1;
+    const char* box_env = getenv("VRT_BOX_RECT");                      // development switch: 0 = every wave tests the box
+    const bool box_off = box_env && box_env[0] == '0';
     if (n > VRT_MAX_BATCH) {
         rc = next_table(c, &tab);
         if (rc != VRT_OK) return rc;
@@ -594,7 +603,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     for (int f = 0; f < n; f++) {
         slots[f].pc = pushes[f]; slots[f].fr = frames[f]; slots[f].rg = raygen_consts(pushes[f]);
         slots[f].shard_rank = (per_frame && shards) ? shards[f].rank : p.sh.rank;
-        slots[f].pad = 0;
+        box_rect(pushes[f], slots[f].box);
+        if (box_off) { slots[f].box[0] = slots[f].box[2] = 0; slots[f].box[1] = slots[f].box[3] = 255; }
     }
     // LDS-staged traversals amortise the staging over a 16x16 tile (4 waves); the others run one 8x8 wave per workgroup,
     // which frees a wave slot the moment a wave finishes instead of when its whole tile does
@@ -628,18 +638,17 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     p.tps_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tps);
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
-    // primary rays only, default traversal, every wave full, a budget the recovery of positions from sideDist is exact for:
-    // the hand-written look-up loop (vrt_traverse.h trace_df_fast)
+    // default traversal and budgets the recovery of positions from sideDist is exact for: the hand-written look-up loop
+    // (vrt_traverse.h trace_df_fast) for every ray of the frame
     {
         const char* e = getenv("VRT_FAST_LOOP");                          // development switch: 0 = off
         const bool want = !(e && e[0] == '0');
         const bool df = st->traversal == VRT_TRAVERSAL_AUTO || st->traversal == VRT_TRAVERSAL_DF;
-        if (want && p.fused_shade == 1 && df && s->d.vol.df_fast && st->max_steps >= 1 && st->max_steps <= 1024 && p.tile_h == 8 &&
-            W % 8 == 0 && H % 8 == 0 && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u))) {
-            bool voxel_plane = false;                             // the fast loop keeps no mapPos: no hit_voxel plane
-            for (int f = 0; f < n; f++) voxel_plane = voxel_plane || frames[f].hit_voxel != nullptr;
-            if (!voxel_plane) p.fused_shade = 3;
-        }
+        const bool sec = p.fused_shade != 1;
+        bool ok = want && df && s->d.vol.df_fast && st->max_steps >= 1 && st->max_steps <= 1024 && p.tile_h == 8 &&
+                  !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (!sec || st->ao_samples == 0 || (st->ao_steps >= 1 && st->ao_steps <= 1024));
+        for (int f = 0; f < n && ok; f++) ok = frames[f].hit_voxel == nullptr;      // the fast loop keeps no mapPos: no hit_voxel plane
+        p.fast_loop = ok ? 1 : 0;
     }
     p.occ2_bytes = s->occ2_bytes; p.occ3_bytes = s->occ3_bytes;
     p.occ_in_lds = ((size_t)s->occ2_bytes + s->occ3_bytes <= 65536) ? 1 : 0;

@@ -159,6 +159,8 @@ hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst,
 struct RayHit {            // RayHit, voxel_volume.frag:43-49
     uint32_t material;
     f3 pos, normal, dir;
+    uint32_t ncode;        // which of the 26 face / edge / corner normals `normal` is: mask | (sx<0)<<3 | (sy<0)<<4 | (sz<0)<<5;
+                           // 0xFFFFFFFF: none of them (the zero vector of rule A, or a masked axis the ray does not move along)
 };
 
 // Occupancy summaries as seen by a workgroup: LDS copies when they fit (typed address_space(3) pointers, so
@@ -183,19 +185,21 @@ __device__ __forceinline__ f3 hit_normal(uint32_t mask, int sx, int sy, int sz)
 }
 
 // traceRay, voxel_volume.frag:176-196
-template <int TRAV, class Occ, bool AHEAD = false, bool FAST = false>
+template <int TRAV, class Occ, bool AHEAD = false>
 __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 start, f3 dir,
                                           uint32_t maxSteps, RayHit& h, RayInt& r)
 {
-    if (FAST) { NoStats ns; trace_df_fast(s.vol, start, dir, maxSteps, r, ns); }
-    else trace_int<TRAV, decltype(occ.o2), AHEAD>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
+    trace_int<TRAV, decltype(occ.o2), AHEAD>(s.vol, occ.o2, occ.o3, start, dir, maxSteps, r);
     h.material = r.material;
     h.dir = dir;
     // values first, one assignment to h afterwards: stores to h from both sides of the branch were being merged into
     // address-selected scratch stores (28 B of scratch per lane, which also slows the wave launch)
     f3 pos = mk3(0.0f, 0.0f, 0.0f), nrm = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t ncode = 0xFFFFFFFFu;
     if (r.material != 0) {
         nrm = hit_normal(r.mask, r.sx, r.sy, r.sz);
+        const bool general = (r.mask & 7u) == 0u || ((r.mask & 1u) && r.sx == 0) || ((r.mask & 2u) && r.sy == 0) || ((r.mask & 4u) && r.sz == 0);
+        if (!general) ncode = (r.mask & 7u) | ((uint32_t)(r.sx < 0) << 3) | ((uint32_t)(r.sy < 0) << 4) | ((uint32_t)(r.sz < 0) << 5);
         f3 m = mk3((r.mask & 1u) ? (r.side.x - r.delta.x) : 0.0f,
                    (r.mask & 2u) ? (r.side.y - r.delta.y) : 0.0f,
                    (r.mask & 4u) ? (r.side.z - r.delta.z) : 0.0f);
@@ -204,6 +208,7 @@ __device__ __forceinline__ void trace_ray(const DevScene& s, const Occ occ, f3 s
     }
     h.pos = pos;
     h.normal = nrm;
+    h.ncode = ncode;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,6 +242,23 @@ __device__ __forceinline__ f3 sky_color(const DevScene& s, f3 d)
     uint32_t x = wrap_texel(u, s.sky_w), y = wrap_texel(v, s.sky_h);
     const float4 t = reinterpret_cast<const float4*>(s.sky)[(size_t)y * s.sky_w + x];
     return mk3(t.x, t.y, t.z);
+}
+
+// skyColor of every normal a hit can have, by sky_color itself (so that the table holds bit for bit what the shading code
+// would compute); entry = mask | (sx<0)<<3 | (sy<0)<<4 | (sz<0)<<5, 64 x float4
+__global__ void k_sky_normals(const DevScene s, float4* table)
+{
+    const uint32_t code = threadIdx.x & 63u, mask = code & 7u;
+    const int sx = (code & 8u) ? -1 : 1, sy = (code & 16u) ? -1 : 1, sz = (code & 32u) ? -1 : 1;
+    f3 c = mk3(0.0f, 0.0f, 0.0f);
+    if (mask != 0u) c = sky_color(s, hit_normal(mask, sx, sy, sz));
+    table[code] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
+hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sky_normals, dim3(1), dim3(64), 0, s, sc, reinterpret_cast<float4*>(table));
+    return hipGetLastError();
 }
 
 // fragmentNoiseSeq + randomDir, voxel_volume.frag:80-95
@@ -333,7 +355,17 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
             if (r.material != 0) ambient += sample_frac;
         }
     }
-    f3 sky = sky_color(s, hit.normal);
+    // skyColor(hit.normal): the normal is one of 26 vectors, whose sky texels the scene holds in a table (computed by this very
+    // function, k_sky_normals); any other normal is looked up here
+    f3 sky;
+#if defined(VRT_NO_SKY_TABLE)
+    if (false) {
+#else
+    if (__ballot(hit.ncode == 0xFFFFFFFFu) == 0ull) {
+#endif
+        const float4 t = reinterpret_cast<const float4*>(s.sky_normals)[hit.ncode];
+        sky = mk3(t.x, t.y, t.z);
+    } else sky = sky_color(s, hit.normal);
     float k = ambient * st.ambient_intensity;
     f3 amb = mk3(k * sky.x, k * sky.y, k * sky.z);
 
@@ -427,9 +459,10 @@ template <int N> __device__ __forceinline__ void table_read(const GeomParams& P,
 }
 template <bool TABLE> struct SlotOf;
 template <> struct SlotOf<false> {
-    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank)
+    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank, uint32_t& box)
     {
         const FrameSlot& S = P.slot[frame];
+        box = (uint32_t)S.box[0] | ((uint32_t)S.box[1] << 8) | ((uint32_t)S.box[2] << 16) | ((uint32_t)S.box[3] << 24);
         g = S.rg;
         cam_pos[0] = S.pc.cam_pos[0]; cam_pos[1] = S.pc.cam_pos[1]; cam_pos[2] = S.pc.cam_pos[2];
         cam_right[0] = S.pc.cam_right[0]; cam_right[1] = S.pc.cam_right[1]; cam_right[2] = S.pc.cam_right[2];
@@ -441,8 +474,9 @@ template <> struct SlotOf<false> {
 // The table form reads the pieces when they are needed, like the kernel-argument form does: a copy of the whole slot at the
 // top keeps the fourteen plane pointers in scalar registers through the traversal (82 + 6 SGPRs: one wave per SIMD less).
 template <> struct SlotOf<true> {
-    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank)
+    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank, uint32_t& box)
     {
+        table_read<1>(P, frame, offsetof(FrameSlot, box), &box);
         table_read<sizeof(RayGenConsts) / 4>(P, frame, offsetof(FrameSlot, rg), &g);
         table_read<3>(P, frame, offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_pos), cam_pos);
         table_read<3>(P, frame, offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_right), cam_right);
@@ -536,8 +570,7 @@ template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomPara
 // K1: primary rays
 // ---------------------------------------------------------------------------------------------
 
-// MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;  3: MODE 1 with the hand-written
-//         look-up loop (trace_df_fast; the host checks its preconditions: every wave full, budget <= 1024, ninth field);
+// MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
@@ -558,7 +591,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     RayGenConsts g;
     float cam_pos[3], cam_right[3];
     int shard_rank;
-    SlotOf<TABLE>::head(P, frame, g, cam_pos, cam_right, shard_rank);
+    uint32_t box;
+    SlotOf<TABLE>::head(P, frame, g, cam_pos, cam_right, shard_rank, box);
+    asm volatile("" : "+s"(box));
+    const uint4 boxr = make_uint4(box & 0xFFu, (box >> 8) & 0xFFu, (box >> 16) & 0xFFu, box >> 24);
     float cpx = cam_pos[0], cpy = cam_pos[1], cpz = cam_pos[2];
     float crx = cam_right[0], cry = cam_right[1], crz = cam_right[2];
     float rcp_w = P.rcp_w, rcp_h = P.rcp_h;
@@ -577,8 +613,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // (A 16x4 block would make every store of the 4-byte planes a full 64-byte line, but measured 3 % slower:
     // the wider footprint lowers the wave-wide clearance minimum by more than the stores gain.)
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int px = x0 + (wave & 1) * 8 + (lane & 7);
-    int py = y0 + (wave >> 1) * 8 + (lane >> 3);
+    const int px0 = x0 + (wave & 1) * 8, py0 = y0 + (wave >> 1) * 8;       // the wave's 8x8 block (wave-uniform)
+    int px = px0 + (lane & 7);
+    int py = py0 + (lane >> 3);
     int W = M.W, H = M.H;
     if (px >= W || py >= H) return;
     size_t i = (size_t)py * (size_t)W + (size_t)px;
@@ -587,7 +624,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     f3 start = mk3(cpx, cpy, cpz);
     f3 dir = primary_dir_fast(g, crx, cry, crz, rcp_w, rcp_h, fast_div, px, py);
     RayHit h; RayInt r;
-    trace_ray<TRAV, OccT<kLds>, MODE == 1, MODE == 3>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
+    // a wave whose 8x8 pixels lie outside the frame's box rectangle (FrameSlot::box, vrt_internal.h box_rect) cannot meet the
+    // volume: it writes what a miss writes without testing the box (wave-uniform: the rectangle is in units of 32 pixels)
+    if ((uint32_t)(px0 >> 5) < boxr.x || (uint32_t)(px0 >> 5) >= boxr.y || (uint32_t)(py0 >> 5) < boxr.z || (uint32_t)(py0 >> 5) >= boxr.w) {
+        h.material = 0u; h.dir = dir; h.pos = mk3(0.0f, 0.0f, 0.0f); h.normal = mk3(0.0f, 0.0f, 0.0f); h.ncode = 0xFFFFFFFFu;
+        r.material = 0u; r.mask = 0u; r.fetches = 0u; r.mx = r.my = r.mz = 0; r.dbg0 = 1u; r.dbg1 = 0u;
+    } else
+    trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
     bool hit = h.material != 0;
 
     const vrt_frame f = SlotOf<TABLE>::planes(P, frame);   // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store
@@ -621,7 +664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         f3 col;
         if (hit) {
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame); c.have_noise = false;
-            if (MODE == 1 || MODE == 3) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
+            if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 col = color_main_ray<TRAV>(P, occ, c, h);
                 if (f.steps_total && !(P.st.flags & 3u)) f.steps_total[i] = r.fetches + c.fetches;
@@ -684,6 +727,10 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;
     PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &P.slot[0].pc; c.have_noise = false;
     h.normal = hit_normal(mask, sx, sy, sz);
+    {
+        const bool general = (mask & 7u) == 0u || ((mask & 1u) && sx == 0) || ((mask & 2u) && sy == 0) || ((mask & 4u) && sz == 0);
+        h.ncode = general ? 0xFFFFFFFFu : ((mask & 7u) | ((uint32_t)(sx < 0) << 3) | ((uint32_t)(sy < 0) << 4) | ((uint32_t)(sz < 0) << 5));
+    }
     f3 col = color_main_ray<TRAV>(P, occ, c, h);
     const vrt_frame& f = P.slot[0].fr;
     if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
@@ -712,11 +759,7 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
     else if (p.xcd_turn) wgs = (unsigned)p.tiles_x * 8u * (unsigned)((p.tiles_y_local * p.n_frames + 7) / 8);
     dim3 grid(wgs), block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
-    if (TRAV == VRT_TRAVERSAL_DF && p.fused_shade == 3) {
-        if (p.table) hipLaunchKernelGGL((k_primary<VRT_TRAVERSAL_DF, false, 3, true>), grid, block, lds, s, p);
-        else         hipLaunchKernelGGL((k_primary<VRT_TRAVERSAL_DF, false, 3, false>), grid, block, lds, s, p);
-    }
-    else if (p.table) {               // the split form renders one frame per launch and never gets here
+    if (p.table) {               // the split form renders one frame per launch and never gets here
         if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, true>), grid, block, lds, s, p);
         else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, true>), grid, block, lds, s, p);
         else return hipErrorInvalidValue;
@@ -738,15 +781,16 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-static int effective_traversal(int t)
+static int effective_traversal(int t, int fast_loop)
 {
     if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP || t == VRT_TRAVERSAL_DFJ) return t;
-    return VRT_TRAVERSAL_DF;        // AUTO / DF
+    return fast_loop ? VRT_TRAVERSAL_DF_FAST : VRT_TRAVERSAL_DF;        // AUTO / DF
 }
 
 hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 {
-    int t = effective_traversal((int)p.st.traversal);
+    int t = effective_traversal((int)p.st.traversal, p.fast_loop);
+    if (t == VRT_TRAVERSAL_DF_FAST) return launch_primary_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_primary_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_DFJ) return launch_primary_t<VRT_TRAVERSAL_DFJ, false>(p, s);
@@ -756,7 +800,8 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 
 hipError_t launch_shade(const GeomParams& p, hipStream_t s)
 {
-    int t = effective_traversal((int)p.st.traversal);
+    int t = effective_traversal((int)p.st.traversal, p.fast_loop);
+    if (t == VRT_TRAVERSAL_DF_FAST) return launch_shade_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_shade_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_DFJ) return launch_shade_t<VRT_TRAVERSAL_DFJ, false>(p, s);
@@ -766,7 +811,7 @@ hipError_t launch_shade(const GeomParams& p, hipStream_t s)
 
 const char* primary_kernel_name(int traversal, int fused, int occ_lds)
 {
-    int t = effective_traversal(traversal);
+    int t = effective_traversal(traversal, 0);
     (void)fused; (void)occ_lds;
     return t == VRT_TRAVERSAL_DENSE ? "k_primary<dense>" : (t == VRT_TRAVERSAL_BITMASK ? "k_primary<bitmask>" : (t == VRT_TRAVERSAL_DF ? "k_primary<df>" : "k_primary<jump>"));
 }

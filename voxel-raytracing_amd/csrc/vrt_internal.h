@@ -21,6 +21,8 @@ struct DevScene {
     VolumeView vol;
     const vrt_material* palette;
     const float*   sky;   uint32_t sky_w, sky_h;
+    const float*   sky_normals;   // 64 x float4: skyColor(n) for the 26 normals a hit can have, index = mask | (sx<0)<<3 |
+                                  // (sy<0)<<4 | (sz<0)<<5 (k_sky_normals; rebuilt whenever the sky changes)
     const uint8_t* noise; uint32_t noise_w, noise_h;
 };
 
@@ -50,6 +52,52 @@ inline RayGenConsts raygen_consts(const vrt_push& pc)
     return g;
 }
 
+// Conservative screen rectangle of the volume for one frame's camera, computed on the host in double precision: the rays
+// through pixels outside it miss the box [-m, dim + m]^3 (m = one voxel) and so, by a margin thousands of times the
+// rounding of the shader's fp32 slab test (frag:109-125), miss the volume: their waves skip the box test altogether and
+// write what a miss writes.  Any doubt -- camera inside or near the box, a corner behind the camera, a degenerate basis --
+// returns the whole screen.
+inline void box_rect(const vrt_push& pc, uint8_t out[4])
+{
+    out[0] = 0; out[1] = 255; out[2] = 0; out[3] = 255;
+    const double W = pc.screen_size[0], H = pc.screen_size[1];
+    const double dim[3] = {(double)pc.volume_bounds[0], (double)pc.volume_bounds[1], (double)pc.volume_bounds[2]};
+    const double cam[3] = {pc.cam_pos[0], pc.cam_pos[1], pc.cam_pos[2]};
+    const double m = 1.0;
+    bool inside = true;
+    for (int a = 0; a < 3; a++) inside = inside && cam[a] >= -2.0 * m && cam[a] <= dim[a] + 2.0 * m;
+    if (inside || !(W >= 1.0) || !(H >= 1.0)) return;
+    // ray of screen position (sx, sy): cd + sx U + sy V + J, as main() builds it (frag:312-319)
+    double cd[3] = {pc.cam_dir[0], pc.cam_dir[1], pc.cam_dir[2]};
+    const double l = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
+    if (!(l > 1e-20) || !(l < 1e20)) return;
+    const double U[3] = {pc.cam_right[0], pc.cam_right[1], pc.cam_right[2]};
+    const double V[3] = {pc.cam_up[0] * H / W, pc.cam_up[1] * H / W, pc.cam_up[2] * H / W};
+    const double C[3] = {cd[0] / l + pc.camera_jitter[0] / W * -2.0, cd[1] / l + pc.camera_jitter[1] / H * 2.0, cd[2] / l};
+    // [U V C] (a, b, lambda)^T = P - cam  by Cramer's rule
+    auto det3 = [](const double* x, const double* y, const double* z) {
+        return x[0] * (y[1] * z[2] - y[2] * z[1]) - y[0] * (x[1] * z[2] - x[2] * z[1]) + z[0] * (x[1] * y[2] - x[2] * y[1]);
+    };
+    const double det = det3(U, V, C);
+    const double scale = (fabs(U[0]) + fabs(U[1]) + fabs(U[2])) * (fabs(V[0]) + fabs(V[1]) + fabs(V[2])) * (fabs(C[0]) + fabs(C[1]) + fabs(C[2]));
+    if (!(fabs(det) > 1e-9 * scale) || !(scale > 0.0)) return;
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int k = 0; k < 8; k++) {
+        const double P[3] = {((k & 1) ? dim[0] + m : -m) - cam[0], ((k & 2) ? dim[1] + m : -m) - cam[1], ((k & 4) ? dim[2] + m : -m) - cam[2]};
+        const double lam = det3(U, V, P) / det, a = det3(P, V, C) / det, b = det3(U, P, C) / det;
+        const double reach = fabs(P[0]) + fabs(P[1]) + fabs(P[2]);
+        if (!(lam > 1e-3 * reach / (fabs(C[0]) + fabs(C[1]) + fabs(C[2]) + 1e-30))) return;      // behind, or too close to, the camera plane
+        const double px = (a / lam + 1.0) * 0.5 * W, py = (b / lam + 1.0) * 0.5 * H;
+        if (!(px == px) || !(py == py)) return;
+        x0 = px < x0 ? px : x0; x1 = px > x1 ? px : x1; y0 = py < y0 ? py : y0; y1 = py > y1 ? py : y1;
+    }
+    const double margin = 4.0;                                     // pixels
+    auto lo = [](double v) { v = floor(v / 32.0); return v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v); };
+    auto hi = [](double v) { v = ceil(v / 32.0); return v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v); };
+    out[0] = (uint8_t)lo(x0 - margin); out[1] = (uint8_t)hi(x1 + margin);
+    out[2] = (uint8_t)lo(y0 - margin); out[3] = (uint8_t)hi(y1 + margin);
+}
+
 // (i + 0.5) / n for i in [0, n) as q = x * r; q += fma(-q, n, x) * r with r = 1 / n: one multiply and two FMAs instead of
 // the ~11 instructions of an IEEE division.  The sequence is the correctly rounded quotient for almost every divisor;
 // whether it is for THIS one is decided by trying all n numerators (the host does so once per screen size).
@@ -76,7 +124,8 @@ struct FrameSlot {
     vrt_push     pc;
     vrt_frame    fr;
     int32_t      shard_rank;
-    int32_t      pad;
+    uint8_t      box[4];       // screen rectangle outside which no primary ray of this frame can meet the volume, in units of
+                               // 32 pixels: columns [box[0], box[1]) x rows [box[2], box[3]) (box_rect(); {0, 255, 0, 255} = all)
 };
 static_assert(sizeof(FrameSlot) == 256, "FrameSlot is sized for aligned scalar loads");
 
@@ -122,8 +171,8 @@ struct GeomParams {
     uint4*     records;        // per-pixel primary hit record for the shading kernel (full-frame indexing)
     uint32_t*  hit_count;      // K1 -> K2: number of hit pixels (zeroed before K1)
     uint32_t*  hit_list;       // K1 -> K2: their pixel indices, in arrival order
-    int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled); 3: the same with the hand-written
-                               // look-up loop; 2: megakernel; 0: split
+    int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled); 2: megakernel; 0: split
+    int32_t    fast_loop;      // 1: AUTO / DF run the hand-written look-up loop (trace_df_fast; the host checked its preconditions)
     int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
     uint32_t   occ2_bytes, occ3_bytes;   // both multiples of 16
 };
@@ -164,6 +213,7 @@ struct BlitParams {
 hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_t* occ1, uint64_t* occ2,
                                 uint64_t* occ3, hipStream_t s);
 hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s);
+hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s);
 hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst, hipStream_t s);
 hipError_t launch_primary(const GeomParams& p, hipStream_t s);
 hipError_t launch_shade(const GeomParams& p, hipStream_t s);

@@ -40,6 +40,7 @@
 #define VRT_TRAVERSAL_DF 4
 #define VRT_TRAVERSAL_DFJ 5
 #endif
+#define VRT_TRAVERSAL_DF_FAST 7   // internal: DF through the hand-written look-up loop (trace_df_fast); chosen by the host
 
 namespace vrt {
 
@@ -772,7 +773,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 // instructions issued between vector ones almost nothing.  So the loop is written for few, cheap VECTOR instructions:
 //  * a finished lane does not leave EXEC: its deltas are zeroed (x + 0 = x: its sideDist stands still), its index points
 //    at a byte that holds 0xFF, so the byte it reads IS its vote -- no select, no "done" mask, no live mask: every
-//    iteration runs with EXEC = all lanes (the kernel guarantees full waves);
+//    iteration runs under the mask the loop was entered with;
 //  * iterations are the EXEC-narrowing form (v_min3, then per axis v_cmpx + v_add under it: 6.9 units; the compare-
 //    select-add form without EXEC writes measured 10.0);
 //  * one compare (byte < 2) answers both "did a lane hit" and "is the run a single iteration" (half of all look-ups);
@@ -783,7 +784,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 //    the running sum's ulp), far below 1/2 for the budgets this path accepts (maxSteps <= 1024: 0.063).  An axis the ray
 //    cannot step along has side = +inf and g = 0: the product is v_mul_legacy_f32's (0 * anything = 0; a NaN would
 //    convert to INT_MIN, tools/ubench/nan_cvt.hip).
-// Preconditions (checked by the host): v.df_fast, 1 <= maxSteps <= 1024, all 64 lanes of the wave active.
+// Preconditions (checked by the host): v.df_fast, 1 <= maxSteps <= 1024.  The loop runs under the EXEC mask it is entered with.
 // Hazards kept by hand inside the block (gfx950): a DPP source needs two wait states after a vector write, a DPP five
 // after a write of EXEC; a scalar pair written by a vector compare needs two before a vector instruction reads it as mask.
 __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
@@ -796,28 +797,28 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
     // EXEC mask that is there anyway -- cheaper than recovering the position afterwards for runs of up to four iterations
     // (three quarters of all runs)
 #define VRT_F_EITER_IDX                                          \
-        "s_mov_b64 exec, -1\n\t"                                  \
+        "s_mov_b64 exec, s[68:69]\n\t"                                  \
         "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
         "v_cmpx_eq_u32 v48, %[x]\n\t"                             \
         "v_add_f32 %[x], %[x], %[dx]\n\t"                         \
         "v_add_u32 v53, v53, %[ix]\n\t"                           \
-        "s_mov_b64 exec, -1\n\t"                                  \
+        "s_mov_b64 exec, s[68:69]\n\t"                                  \
         "v_cmpx_eq_u32 v48, %[y]\n\t"                             \
         "v_add_f32 %[y], %[y], %[dy]\n\t"                         \
         "v_add_u32 v53, v53, %[iy]\n\t"                           \
-        "s_mov_b64 exec, -1\n\t"                                  \
+        "s_mov_b64 exec, s[68:69]\n\t"                                  \
         "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
         "v_add_f32 %[z], %[z], %[dz]\n\t"                         \
         "v_add_u32 v53, v53, %[iz]\n\t"
 #define VRT_F_EITER                                              \
-        "s_mov_b64 exec, -1\n\t"                                  \
+        "s_mov_b64 exec, s[68:69]\n\t"                                  \
         "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
         "v_cmpx_eq_u32 v48, %[x]\n\t"                             \
         "v_add_f32 %[x], %[x], %[dx]\n\t"                         \
-        "s_mov_b64 exec, -1\n\t"                                  \
+        "s_mov_b64 exec, s[68:69]\n\t"                                  \
         "v_cmpx_eq_u32 v48, %[y]\n\t"                             \
         "v_add_f32 %[y], %[y], %[dy]\n\t"                         \
-        "s_mov_b64 exec, -1\n\t"                                  \
+        "s_mov_b64 exec, s[68:69]\n\t"                                  \
         "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
         "v_add_f32 %[z], %[z], %[dz]\n\t"
     // scalars of the block: s60 = i (iterations done by every live lane), s61 = kw, s62 = left / iterations still to do,
@@ -826,6 +827,10 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
     asm volatile(
         "s_mov_b32 s60, 0\n\t"
         "s_movk_i32 s63, 0xff\n\t"
+        // the loop runs under the EXEC mask it is entered with (all 64 lanes for primary rays; the hit lanes of a wave for its
+        // secondary rays): no instruction here may write a lane outside it -- the compiler lets the registers of this block
+        // hold live values of the OTHER lanes of a divergent branch (SIOptimizeVGPRLiveRange)
+        "s_mov_b64 s[68:69], exec\n\t"
         "v_mov_b32 v53, %[idx0]\n\t"
         "global_load_ubyte v52, v53, %[base]\n\t"
         "10:\n\t"                                                   // ---- look-up: every lane's byte is here ----
@@ -835,6 +840,8 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_cbranch_vccnz 15f\n\t"
         "v_cmp_gt_u32_e32 vcc, 4, v52\n\t"                          // 2 or 3 somewhere (and nothing below)?
         "s_cbranch_vccnz 16f\n\t"
+        "s_cmp_eq_u64 s[68:69], -1\n\t"
+        "s_cbranch_scc0 14f\n\t"                                    // a partly filled wave: no DPP reduction (lane 63 may be off)
         "v_mov_b32 v48, v52\n\t"                                    // wave minimum of the votes: every live lane has >= 4
         "s_nop 1\n\t"
         "v_min_u32_dpp v48, v48, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -854,6 +861,7 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_nop 1\n\t"
         "s_cmp_eq_u32 s61, s63\n\t"
         "s_cbranch_scc1 40f\n\t"                                    // nobody is live: done
+        "13:\n\t"
         "s_min_u32 s61, s61, s62\n\t"
         "s_cmp_le_u32 s61, 4\n\t"
         "s_cbranch_scc1 18f\n\t"
@@ -882,20 +890,20 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_sub_u32 s62, s62, 1\n\t"                                 // SCC = borrow: that was the last quad
         "s_cbranch_scc0 33b\n\t"
         "34:\n\t"                                                   // the run's last iteration: its EXEC masks are the mask bits
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
         "v_cmpx_eq_u32 v48, %[x]\n\t"
         "s_mov_b64 %[kx], exec\n\t"
         "v_add_f32 %[x], %[x], %[dx]\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         "v_cmpx_eq_u32 v48, %[y]\n\t"
         "s_mov_b64 %[ky], exec\n\t"
         "v_add_f32 %[y], %[y], %[dy]\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         "v_cmpx_eq_u32 v48, %[z]\n\t"
         "s_mov_b64 %[kz], exec\n\t"
         "v_add_f32 %[z], %[z], %[dz]\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         // ---- where is every lane now?  request its next byte ----
         "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"                     // (legacy: inf * 0 = 0, an axis the ray cannot step along)
         "v_mul_legacy_f32 v49, %[y], %[gy]\n\t"
@@ -923,6 +931,37 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "v_mov_b32 %[fet], s60\n\t"
         "s_mov_b64 exec, s[66:67]\n\t"
         "s_branch 40f\n\t"
+        "14:\n\t"                                                   // ---- minimum of a partly filled wave: binary search by votes ----
+        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t"
+        "s_cbranch_vccz 40f\n\t"                                    // nobody is live: done
+        "v_min_u32 v48, 63, v52\n\t"                                // (a finished lane: 63, never below a live one)
+        "s_sub_u32 s62, %[maxs], s60\n\t"
+        "s_mov_b32 s61, 0\n\t"
+        "s_or_b32 s66, s61, 32\n\t"
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
+        "s_cmp_eq_u64 vcc, 0\n\t"
+        "s_cselect_b32 s61, s66, s61\n\t"
+        "s_or_b32 s66, s61, 16\n\t"
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
+        "s_cmp_eq_u64 vcc, 0\n\t"
+        "s_cselect_b32 s61, s66, s61\n\t"
+        "s_or_b32 s66, s61, 8\n\t"
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
+        "s_cmp_eq_u64 vcc, 0\n\t"
+        "s_cselect_b32 s61, s66, s61\n\t"
+        "s_or_b32 s66, s61, 4\n\t"
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
+        "s_cmp_eq_u64 vcc, 0\n\t"
+        "s_cselect_b32 s61, s66, s61\n\t"
+        "s_or_b32 s66, s61, 2\n\t"
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
+        "s_cmp_eq_u64 vcc, 0\n\t"
+        "s_cselect_b32 s61, s66, s61\n\t"
+        "s_or_b32 s66, s61, 1\n\t"
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
+        "s_cmp_eq_u64 vcc, 0\n\t"
+        "s_cselect_b32 s61, s66, s61\n\t"
+        "s_branch 13b\n\t"
         "16:\n\t"                                                   // ---- the smallest vote is 2 or 3 ----
         "v_cmp_eq_u32_e32 vcc, 2, v52\n\t"
         "s_sub_u32 s62, %[maxs], s60\n\t"
@@ -945,23 +984,23 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "183:\n\t"
         VRT_F_EITER_IDX
         "184:\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
         "v_cmpx_eq_u32 v48, %[x]\n\t"
         "s_mov_b64 %[kx], exec\n\t"
         "v_add_f32 %[x], %[x], %[dx]\n\t"
         "v_add_u32 v53, v53, %[ix]\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         "v_cmpx_eq_u32 v48, %[y]\n\t"
         "s_mov_b64 %[ky], exec\n\t"
         "v_add_f32 %[y], %[y], %[dy]\n\t"
         "v_add_u32 v53, v53, %[iy]\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         "v_cmpx_eq_u32 v48, %[z]\n\t"
         "s_mov_b64 %[kz], exec\n\t"
         "v_add_f32 %[z], %[z], %[dz]\n\t"
         "v_add_u32 v53, v53, %[iz]\n\t"
-        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         "global_load_ubyte v52, v53, %[base]\n\t"
         "s_cmp_lt_u32 s60, %[maxs]\n\t"
         "s_cbranch_scc1 10b\n\t"
@@ -998,13 +1037,14 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_branch 11b\n\t"                                          // the other lanes' bytes are still to be looked at
         "40:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
         : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
           [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
           [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), [fet] "+v"(fetches),
           [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz)
         : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53",
-          "s60", "s61", "s62", "s63", "s66", "s67");
+          "s60", "s61", "s62", "s63", "s66", "s67", "s68", "s69");
 #undef VRT_F_EITER
 #undef VRT_F_EITER_IDX
 }
@@ -1037,16 +1077,22 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     float x = s.sdx, y = s.sdy, z = s.sdz;
     // what one step along an axis adds to the index (0 for a lane that never enters the volume)
     const int incx = done0 ? 0 : s.sx, incy = done0 ? 0 : s.sy * pw, incz = done0 ? 0 : s.sz * pwh;
-    df_fast_loop(v.df, maxSteps, pw, pwh, sentinel, x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
+    // the block's scalar operands must BE in scalar registers: values that are uniform but were computed under divergent
+    // control flow (secondary rays) may live in vector registers
+    const uint64_t b64 = (uint64_t)v.df;
+    const uint8_t* base = (const uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
+                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));      // (the builtin returns int)
+    df_fast_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
                  incx, incy, incz);
     s.sdx = x; s.sdy = y; s.sdz = z;
     finish(s, material, lmask, fetches + (material != 0u ? 1u : 0u), r);
     (void)stats;
 }
-#elif defined(__HIPCC__)
-// host pass of a .hip file: device functions are parsed, never run
+#else
+// host pass of a .hip file / the host build of the unit tests: parsed, never run (the loop is gfx950 assembly)
 template <class STATS>
-__device__ void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
+VRT_HD void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 #endif
 
 template <class STATS, bool AHEAD = false>
@@ -1399,6 +1445,9 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
     if (TRAV == VRT_TRAVERSAL_JUMP) {
         NoStats ns;
         trace_jump(v, o2, o3, start, dir, maxSteps, r, ns);
+    } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
+        NoStats ns;
+        trace_df_fast(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF) {
         NoStats ns;
         trace_df<NoStats, AHEAD>(v, start, dir, maxSteps, r, ns);
