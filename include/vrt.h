@@ -68,6 +68,7 @@ typedef struct vrt_push {
 #define VRT_TRAVERSAL_JUMP    3   /* BITMASK + exact closed-form jumps across empty pyramid cells */
 #define VRT_TRAVERSAL_DF      4   /* octant clearance, its minimum over the wave agreed by a DPP reduction; ALU-only runs between look-ups */
 #define VRT_TRAVERSAL_DFJ     5   /* DF with the long runs (clearance >= 12) done per lane in closed form (JUMP's integer form) */
+/* (6, 7: internal -- the brick-scene march and the hand-written DF loop; both are what AUTO resolves to where they apply) */
 
 #define VRT_FLAG_SPLIT_KERNELS 4u /* trace secondary rays in a second kernel (K2) over the compacted hit list instead of inside K1 */
 #define VRT_FLAG_DEBUG_PLANES 1u  /* steps_total / rays_total receive traversal diagnostics instead (development aid) */
@@ -154,6 +155,16 @@ int  vrt_scene_load_vox_mem(vrt_ctx* ctx, const void* buf, size_t n, vrt_scene**
 /* Synthetic scenes: dense R8 volume, index x + y*W + z*W*H (Texture3D upload order, voxel_scene.cpp:99,122). */
 int  vrt_scene_from_dense(vrt_ctx* ctx, const uint8_t* voxels, uint32_t W, uint32_t H, uint32_t D,
                           const vrt_material palette[256], vrt_scene** out);
+/* The same volume handed over SPARSELY, in 8^3 bricks (no reference analogue: the reference's Texture3D is dense,
+ * voxel_scene.cpp:77-78,122; BASELINE configs[4] is a 2048^3 volume -- 8 GiB dense, 9x that with the dense scene's clearance
+ * fields).  grid[bx + by*nbx + bz*nbx*nby] = 0 for an empty brick, else 1 + its index in `pool`; pool holds n_bricks x 512
+ * voxel ids, voxel (x,y,z) of a brick at x + 8y + 64z.  The scene is the W x H x D = 8nbx x 8nby x 8nbz volume those bricks
+ * spell out, and renders bit for bit like vrt_scene_from_dense of the same content; device memory is per OCCUPIED brick
+ * (4.5 KiB: ids + per-voxel clearance) plus 12 bytes per brick of the grid.  Only VRT_TRAVERSAL_AUTO applies to it. */
+int  vrt_scene_from_bricks(vrt_ctx* ctx, const uint32_t* grid, uint32_t nbx, uint32_t nby, uint32_t nbz,
+                           const uint8_t* pool, uint32_t n_bricks, const vrt_material palette[256], vrt_scene** out);
+/* Device bytes a scene holds (volume, clearance, pyramid / brick structures, palette, sky, noise). */
+int  vrt_scene_memory(const vrt_scene* sc, uint64_t* bytes);
 /* Host-only half of the loader (no device needed): parse + flatten into malloc'd host memory.
  * *voxels must be released with vrt_host_free.  Used by tests and by the C++ host mirror. */
 int  vrt_vox_flatten_host(const void* buf, size_t n, uint32_t dims[3], uint8_t** voxels,

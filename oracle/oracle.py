@@ -23,7 +23,8 @@ class Push(C.Structure):
 class Scene(C.Structure):
     _fields_ = [("voxels", C.c_void_p), ("dims", C.c_uint32 * 3), ("palette", C.c_void_p),
                 ("sky", C.c_void_p), ("sky_w", C.c_uint32), ("sky_h", C.c_uint32),
-                ("noise", C.c_void_p), ("noise_w", C.c_uint32), ("noise_h", C.c_uint32)]
+                ("noise", C.c_void_p), ("noise_w", C.c_uint32), ("noise_h", C.c_uint32),
+                ("brick_grid", C.c_void_p), ("brick_pool", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -113,16 +114,29 @@ def jitter(index, render_width, display_width):
 class OracleScene:
     """Host copy of a scene for the oracle.  voxels[z,y,x] uint8, palette (256,5) float32 (r,g,b,a,metallic)."""
 
-    def __init__(self, voxels, palette, sky=None, noise=None):
-        self.voxels = np.ascontiguousarray(voxels, dtype=np.uint8)
-        D, H, W = self.voxels.shape
+    def __init__(self, voxels, palette, sky=None, noise=None, bricks=None):
+        """bricks = (grid uint32 [nbz, nby, nbx], pool uint8 [n, 8, 8, 8]): the volume in 8^3 bricks instead of `voxels`
+        (pass voxels=None); get_voxel then reads through the brick grid."""
+        if bricks is not None:
+            self.grid = np.ascontiguousarray(bricks[0], dtype=np.uint32)
+            self.pool = np.ascontiguousarray(bricks[1], dtype=np.uint8)
+            self.voxels = None
+            D, H, W = (8 * n for n in self.grid.shape)
+        else:
+            self.voxels = np.ascontiguousarray(voxels, dtype=np.uint8)
+            D, H, W = self.voxels.shape
         pal = np.zeros((256, 8), dtype=np.float32)
         pal[:, :5] = np.asarray(palette, dtype=np.float32)
         self.palette = pal
         self.sky = np.ascontiguousarray(sky if sky is not None else np.ones((1, 1, 4), np.float32), dtype=np.float32)
         self.noise = np.ascontiguousarray(noise if noise is not None else np.array([[[128, 128, 128, 255]]], np.uint8), dtype=np.uint8)
         s = Scene()
-        s.voxels = self.voxels.ctypes.data
+        if self.voxels is not None:
+            s.voxels = self.voxels.ctypes.data
+        else:
+            s.voxels = None
+            s.brick_grid = self.grid.ctypes.data
+            s.brick_pool = self.pool.ctypes.data if self.pool.size else None
         s.dims[:] = [W, H, D]
         s.palette = self.palette.ctypes.data
         s.sky = self.sky.ctypes.data; s.sky_w = self.sky.shape[1]; s.sky_h = self.sky.shape[0]

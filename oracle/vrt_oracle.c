@@ -166,6 +166,12 @@ typedef struct ray_hit {          /* RayHit, voxel_volume.frag:43-49 */
 static inline uint32_t get_voxel(const vo_scene* sc, const int p[3])
 {
     size_t W = sc->dims[0], H = sc->dims[1];
+    if (!sc->voxels) {                                        /* brick storage of the same texture */
+        size_t nbx = W / 8, nby = H / 8;
+        uint32_t b = sc->brick_grid[(size_t)(p[0] >> 3) + ((size_t)(p[1] >> 3) + (size_t)(p[2] >> 3) * nby) * nbx];
+        if (b == 0) return 0;
+        return sc->brick_pool[(size_t)(b - 1) * 512 + (size_t)(p[0] & 7) + (size_t)(p[1] & 7) * 8 + (size_t)(p[2] & 7) * 64];
+    }
     return sc->voxels[(size_t)p[0] + (size_t)p[1] * W + (size_t)p[2] * W * H];
 }
 

@@ -58,6 +58,12 @@ typedef struct vo_scene {
     uint32_t           sky_w, sky_h;
     const uint8_t*     noise;       /* RGBA8, noise_w*noise_h*4 */
     uint32_t           noise_w, noise_h;
+    /* The same volume stored sparsely (voxels == NULL): 8^3 bricks.  brick_grid[bx + by*nbx + bz*nbx*nby] = 0 for an empty
+     * brick, else 1 + index into brick_pool (512 bytes per brick, voxel (x,y,z) of the brick at x + 8y + 64z).  A storage
+     * format only: getVoxel returns what the dense texture of the same content would (BASELINE configs[4]: a 2048^3
+     * volume is 8 GiB dense). */
+    const uint32_t*    brick_grid;
+    const uint8_t*     brick_pool;
 } vo_scene;
 
 /* Parameters + Light UBOs (voxel_volume.frag:57-65) and the shader's compile-time constants

@@ -172,3 +172,21 @@ def test_shading_known_answer(oracle, vrt):
     assert np.allclose(out["color_f"][0, 0], exp, rtol=1e-6)
     assert (out["normal8"][..., 2] == -127).all() and (out["mask8"] == 230).all()
     assert np.allclose(out["depth"], np.linalg.norm(out["position"][..., :3] - np.array([4.3, 4.2, -2.0], np.float32), axis=-1), rtol=1e-6)
+
+
+def test_oracle_brick_storage_equals_dense(vrt, oracle):
+    """vo_scene's brick storage (8^3 brick pool + pointer grid; getVoxel reads through it) is the same texture: a frame of the
+    same content rendered from both storages is identical, plane by plane."""
+    from helpers import camera_push, compare_planes, metallic_palette
+    grid, pool = vrt.synthetic.sparse_brick_scene(64, 0.08, seed=3)
+    vol = vrt.synthetic.dense_from_bricks(grid, pool)
+    g2, p2 = vrt.synthetic.bricks_from_dense(vol)
+    assert (g2 == grid).all() and (p2 == pool).all() and 0 < pool.shape[0] < grid.size
+    pal = metallic_palette(vrt)
+    st = vrt.VoxelRenderSettings(targetResolution=(48, 40))
+    st.fsrSetttings.enable = False
+    push = camera_push(vrt, (64, 64, 64), (48, 40), frame=2)
+    a = oracle.render(oracle.OracleScene(vol, pal), push, oracle.params_from(st.to_c()), nthreads=4)
+    b = oracle.render(oracle.OracleScene(None, pal, bricks=(grid, pool)), push, oracle.params_from(st.to_c()), nthreads=4)
+    assert not compare_planes(a, b, list(a.keys()))
+    assert (a["hit_id"] != 0).mean() > 0.05

@@ -76,6 +76,8 @@ SYMBOLS = {
     "vrt_scene_load_vox_file": (C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
     "vrt_scene_load_vox_mem": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
     "vrt_scene_from_dense": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Material), C.POINTER(_P)]),
+    "vrt_scene_from_bricks": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(Material), C.POINTER(_P)]),
+    "vrt_scene_memory": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "vrt_vox_flatten_host": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(Material),
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "vrt_host_free": (None, [_P]),

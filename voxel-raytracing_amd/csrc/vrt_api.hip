@@ -69,6 +69,10 @@ struct vrt_scene {
     uint8_t* noise = nullptr;
     float* sky_normals = nullptr;
     uint32_t occ2_bytes = 0, occ3_bytes = 0;
+    // brick scenes
+    uint32_t* bgrid = nullptr; uint8_t* bcoarse = nullptr; uint8_t* bpool = nullptr; uint8_t* bfine = nullptr;
+    bool bricks = false;
+    uint64_t bytes = 0;                // device memory held (volume structures + textures)
 };
 
 extern "C" {
@@ -211,6 +215,10 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->sky) hipFree(s->sky);
     if (s->noise) hipFree(s->noise);
     if (s->sky_normals) hipFree(s->sky_normals);
+    if (s->bgrid) hipFree(s->bgrid);
+    if (s->bcoarse) hipFree(s->bcoarse);
+    if (s->bpool) hipFree(s->bpool);
+    if (s->bfine) hipFree(s->bfine);
     delete s;
 }
 
@@ -266,6 +274,18 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     size_t n3pad = (n3 + 1) & ~(size_t)1;
     size_t ndf = df_field_bytes(d.W, d.H, d.D);    // one clearance field: x-fastest with a one-voxel border of zeros
     int rc = VRT_OK;
+    {
+        // the dense scene holds about 10x the voxel bytes (eight or nine clearance fields) and two more volumes while it is
+        // built: say so up front instead of failing half way through the allocations
+        const uint64_t need = (uint64_t)nvox * 3u + 9ull * ndf + (n1 + n2pad + n3pad) * 8ull + (64ull << 20);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (uint64_t)free_b) {
+            delete s;
+            return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_from_dense: a " + std::to_string(W) + "x" + std::to_string(H) + "x" + std::to_string(D) +
+                        " dense scene needs " + std::to_string(need) + " bytes of device memory (" + std::to_string((uint64_t)free_b) +
+                        " free); hand the volume over in bricks (vrt_scene_from_bricks)");
+        }
+    }
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
     SCHK(hipMalloc((void**)&s->vox, nvox));
     SCHK(hipMalloc((void**)&s->occ1, n1 * 8));
@@ -278,6 +298,7 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
         const bool fast = 9ull * ndf + 256ull <= 0xFFFFFFFFull && ((uint64_t)W + 2u) * ((uint64_t)H + 2u) < (1ull << 23);
         const size_t bytes = fast ? 9 * ndf + 256 : 8 * ndf;
         SCHK(hipMalloc((void**)&s->df, bytes));
+        s->bytes = (uint64_t)nvox + bytes + (n1 + n2pad + n3pad) * 8ull + 256 * sizeof(vrt_material);
         SCHK(hipMemsetAsync(s->df, 0, bytes, c->stream));
         if (fast) SCHK(hipMemsetAsync(s->df + 9 * ndf, 0xFF, 1, c->stream));
         d.df_fast = fast ? 1u : 0u;
@@ -312,6 +333,93 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
 bad:
     vrt_scene_free(c, s);
     return rc;
+}
+
+int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32_t nby, uint32_t nbz,
+                          const uint8_t* pool, uint32_t n_bricks, const vrt_material palette[256], vrt_scene** out)
+{
+    if (!c || !grid || !palette || !out || (n_bricks && !pool)) return fail(VRT_ERR_INVALID, "vrt_scene_from_bricks: NULL argument");
+    if (!nbx || !nby || !nbz || nbx > 512 || nby > 512 || nbz > 512)
+        return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_from_bricks: each dimension must be 1..512 bricks (8..4096 voxels)");
+    const size_t nb = (size_t)nbx * nby * nbz;
+    // the brick a pool entry belongs to, as an index into the padded grid; every entry must be referenced exactly once
+    std::vector<uint32_t> coord(n_bricks, 0xFFFFFFFFu);
+    const size_t pbx = (size_t)nbx + 2, pby = (size_t)nby + 2, pbz = (size_t)nbz + 2, npad = pbx * pby * pbz;
+    for (size_t i = 0; i < nb; i++) {
+        const uint32_t g = grid[i];
+        if (g == 0u) continue;
+        if (g > n_bricks) return fail(VRT_ERR_INVALID, "vrt_scene_from_bricks: a grid entry points past the pool");
+        if (coord[g - 1u] != 0xFFFFFFFFu) return fail(VRT_ERR_INVALID, "vrt_scene_from_bricks: two grid entries share a pool brick");
+        const size_t x = i % nbx, y = (i / nbx) % nby, z = i / ((size_t)nbx * nby);
+        coord[g - 1u] = (uint32_t)((x + 1) + ((y + 1) + (z + 1) * pby) * pbx);
+    }
+    for (uint32_t i = 0; i < n_bricks; i++)
+        if (coord[i] == 0xFFFFFFFFu) return fail(VRT_ERR_INVALID, "vrt_scene_from_bricks: a pool brick is not referenced by the grid");
+    HIPCHK(hipSetDevice(c->device));
+    vrt_scene* s = new vrt_scene();
+    s->bricks = true;
+    VolumeView& d = s->d.vol;
+    d.W = (int)(nbx * 8u); d.H = (int)(nby * 8u); d.D = (int)(nbz * 8u);
+    d.pbx = (int)pbx; d.pby = (int)pby;
+    const size_t cstride = df_field_bytes((int)nbx, (int)nby, (int)nbz);          // one padded coarse field (= npad rounded up to 256 B)
+    const size_t pool_bytes = (size_t)n_bricks * 512u, fine_bytes = pool_bytes * 8u;
+    uint32_t *grid_dev = nullptr, *coord_dev = nullptr;
+    uint8_t *occ = nullptr, *tmp0 = nullptr, *tmp1 = nullptr;
+    int rc = VRT_OK;
+#define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
+    SCHK(hipMalloc((void**)&s->bgrid, npad * 4));
+    SCHK(hipMalloc((void**)&s->bcoarse, 8 * cstride));
+    SCHK(hipMalloc((void**)&s->bpool, pool_bytes ? pool_bytes : 1));
+    SCHK(hipMalloc((void**)&s->bfine, fine_bytes ? fine_bytes : 1));
+    SCHK(hipMalloc((void**)&s->palette, 256 * sizeof(vrt_material)));
+    SCHK(hipMalloc((void**)&grid_dev, nb * 4));
+    SCHK(hipMalloc((void**)&coord_dev, (size_t)(n_bricks ? n_bricks : 1) * 4));
+    SCHK(hipMalloc((void**)&occ, nb));
+    SCHK(hipMalloc((void**)&tmp0, nb));
+    SCHK(hipMalloc((void**)&tmp1, nb));
+    s->bytes = npad * 4ull + 8ull * cstride + pool_bytes + fine_bytes + 256 * sizeof(vrt_material);
+    SCHK(hipMemsetAsync(s->bgrid, 0xFF, npad * 4, c->stream));                  // border: 0xFFFFFFFF = outside the volume
+    SCHK(hipMemsetAsync(s->bcoarse, 0, 8 * cstride, c->stream));
+    SCHK(hipMemcpyAsync(grid_dev, grid, nb * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_bricks) {
+        SCHK(hipMemcpyAsync(coord_dev, coord.data(), (size_t)n_bricks * 4, hipMemcpyHostToDevice, c->stream));
+        SCHK(hipMemcpyAsync(s->bpool, pool, pool_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
+    SCHK(launch_brick_grid(grid_dev, (int)nbx, (int)nby, (int)nbz, s->bgrid, occ, c->stream));
+    // brick-level clearance: the dense scene's transform over the occupancy of the bricks, capped at 16 bricks
+    SCHK(launch_build_df(occ, (int)nbx, (int)nby, (int)nbz, s->bcoarse, cstride, tmp0, tmp1, c->stream, 16));
+    SCHK(launch_brick_fine(s->bgrid, (int)pbx, (int)pby, coord_dev, n_bricks, s->bpool, s->bfine, c->stream));
+    SCHK(hipStreamSynchronize(c->stream));
+#undef SCHK
+    hipFree(grid_dev); hipFree(coord_dev); hipFree(occ); hipFree(tmp0); hipFree(tmp1);
+    grid_dev = coord_dev = nullptr; occ = tmp0 = tmp1 = nullptr;
+    d.bgrid = s->bgrid; d.bcoarse = s->bcoarse; d.bcoarse_stride = cstride; d.bpool = s->bpool; d.bfine = s->bfine;
+    s->d.palette = s->palette;
+    {
+        const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        const uint8_t grey[4] = {128, 128, 128, 255};
+        rc = vrt_scene_set_sky(c, s, white, 1, 1);
+        if (rc == VRT_OK) rc = vrt_scene_set_blue_noise(c, s, grey, 1, 1);
+        if (rc != VRT_OK) goto bad;
+    }
+    *out = s;
+    return VRT_OK;
+bad:
+    if (grid_dev) hipFree(grid_dev);
+    if (coord_dev) hipFree(coord_dev);
+    if (occ) hipFree(occ);
+    if (tmp0) hipFree(tmp0);
+    if (tmp1) hipFree(tmp1);
+    vrt_scene_free(c, s);
+    return rc;
+}
+
+int vrt_scene_memory(const vrt_scene* s, uint64_t* bytes)
+{
+    if (!s || !bytes) return fail(VRT_ERR_INVALID, "vrt_scene_memory: NULL argument");
+    *bytes = s->bytes + (uint64_t)s->d.sky_w * s->d.sky_h * 16u + (uint64_t)s->d.noise_w * s->d.noise_h * 4u + 64u * 16u;
+    return VRT_OK;
 }
 
 int vrt_vox_flatten_host(const void* buf, size_t n, uint32_t dims[3], uint8_t** voxels,
@@ -427,6 +535,7 @@ int vrt_scene_info(const vrt_scene* s, uint32_t dims[3])
 int vrt_scene_download(vrt_ctx* c, const vrt_scene* s, uint8_t* voxels, vrt_material palette[256])
 {
     if (!c || !s) return fail(VRT_ERR_INVALID, "vrt_scene_download: NULL argument");
+    if (s->bricks && voxels) return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_download: a brick scene has no dense volume to copy back");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (voxels) HIPCHK(hipMemcpy(voxels, s->vox, (size_t)s->d.vol.W * s->d.vol.H * s->d.vol.D, hipMemcpyDeviceToHost));
@@ -554,6 +663,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     }
     if (st->max_bounces > VRT_MAX_BOUNCES) return fail(VRT_ERR_INVALID, "vrt_render_geometry: max_bounces > VRT_MAX_BOUNCES");
     if (st->traversal > VRT_TRAVERSAL_DFJ) return fail(VRT_ERR_INVALID, "vrt_render_geometry: unknown traversal");
+    if (s->bricks && st->traversal != VRT_TRAVERSAL_AUTO)
+        return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: a brick scene (vrt_scene_from_bricks) renders with VRT_TRAVERSAL_AUTO only");
     if (st->traversal == VRT_TRAVERSAL_DENSE && (uint64_t)s->d.vol.W * (uint64_t)s->d.vol.H * (uint64_t)s->d.vol.D > 0xFFFFFFFFull)
         return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: VRT_TRAVERSAL_DENSE indexes voxels in 32 bits (volumes below 4 GiB)");
     HIPCHK(hipSetDevice(c->device));
@@ -573,6 +684,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     GeomParams p;
     memset(&p, 0, sizeof p);
     p.sc = s->d; p.st = *st;
+    if (s->bricks) p.st.traversal = VRT_TRAVERSAL_BRICK;
     p.n_frames = n; p.W = W; p.H = H;
     if (c->div_w != W || c->div_h != H) { c->div_ok = (screen_div_exact(W) && screen_div_exact(H)) ? 1 : 0; c->div_w = W; c->div_h = H; }
     p.rcp_w = 1.0f / (float)W; p.rcp_h = 1.0f / (float)H; p.fast_screen_div = c->div_ok;

@@ -96,7 +96,7 @@ hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_
 
 // src == nullptr: first pass, the field is (vox != 0 ? 0 : INF).
 __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox, const uint8_t* __restrict__ src,
-                                                 uint8_t* __restrict__ dst, int W, int H, int D, int axis, int dir, int padded)
+                                                 uint8_t* __restrict__ dst, int W, int H, int D, int axis, int dir, int padded, int cap)
 {
     size_t n = (size_t)W * H * D;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox
     int pos = axis == 0 ? x : (axis == 1 ? y : z);
     int dim = axis == 0 ? W : (axis == 1 ? H : D);
     long long stride = (axis == 0 ? 1 : (axis == 1 ? (long long)W : (long long)W * H)) * dir;
-    int best = src ? (int)src[i] : (vox[i] != 0 ? 0 : VRT_DF_CAP + 1);
+    int best = src ? (int)src[i] : (vox[i] != 0 ? 0 : cap + 1);
     for (int t = 1; t < best; t++) {
         int q = pos + t * dir;
         int val = (q < 0 || q >= dim) ? 0
-                                      : (src ? (int)src[(long long)i + t * stride] : (vox[(long long)i + t * stride] != 0 ? 0 : VRT_DF_CAP + 1));
+                                      : (src ? (int)src[(long long)i + t * stride] : (vox[(long long)i + t * stride] != 0 ? 0 : cap + 1));
         int m = val > t ? val : t;
         best = best < m ? best : m;
     }
@@ -117,20 +117,128 @@ __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox
     if (padded) {                                            // final pass: into the zero-bordered field (vrt_traverse.h df_index)
         o = (size_t)(x + 1) + ((size_t)(y + 1) + (size_t)(z + 1) * ((size_t)H + 2u)) * ((size_t)W + 2u);
     }
-    dst[o] = (uint8_t)(best > VRT_DF_CAP ? VRT_DF_CAP : best);
+    dst[o] = (uint8_t)(best > cap ? cap : best);
 }
 
 // df: 8 * stride bytes (stride = df_field_bytes: one zero-bordered field); tmp0/tmp1: W*H*D bytes each
-hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s)
+hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int cap)
 {
     size_t n = (size_t)W * H * D;
     unsigned blocks = (unsigned)((n + 255) / 256);
     for (int o = 0; o < 8; o++) {
         int sx = (o & 1) ? 1 : -1, sy = (o & 2) ? 1 : -1, sz = (o & 4) ? 1 : -1;
-        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)nullptr, tmp0, W, H, D, 0, sx, 0);
-        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp0, tmp1, W, H, D, 1, sy, 0);
-        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp1, df + (size_t)o * stride, W, H, D, 2, sz, 1);
+        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)nullptr, tmp0, W, H, D, 0, sx, 0, cap);
+        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp0, tmp1, W, H, D, 1, sy, 0, cap);
+        hipLaunchKernelGGL(k_df_pass, dim3(blocks), dim3(256), 0, s, vox, (const uint8_t*)tmp1, df + (size_t)o * stride, W, H, D, 2, sz, 1, cap);
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// brick scenes (vrt_scene_from_bricks): padded pointer grid, brick occupancy, per-voxel clearance of the occupied bricks
+// ---------------------------------------------------------------------------------------------
+
+// grid (nbx * nby * nbz) -> interior of the padded grid ((nbx+2)(nby+2)(nbz+2); its border was preset to 0xFFFFFFFF = outside
+// the volume) and one byte per brick: occupied or not
+__global__ __launch_bounds__(256) void k_brick_grid(const uint32_t* __restrict__ grid, int nbx, int nby, int nbz,
+                                                    uint32_t* __restrict__ padded, uint8_t* __restrict__ occ)
+{
+    const size_t n = (size_t)nbx * nby * nbz, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % (size_t)nbx), y = (int)((i / (size_t)nbx) % (size_t)nby), z = (int)(i / ((size_t)nbx * nby));
+    const uint32_t g = grid[i];
+    padded[(size_t)(x + 1) + ((size_t)(y + 1) + (size_t)(z + 1) * ((size_t)nby + 2u)) * ((size_t)nbx + 2u)] = g;
+    occ[i] = g != 0u ? 1 : 0;
+}
+
+// One workgroup per occupied brick: the clearance of each of its voxels in each octant, looking through the 26 neighbours
+// (24^3 voxels in LDS; beyond them -- and outside the volume -- counts as solid, so values reach 9..16).  Per octant the
+// three one-sided min-max passes of k_df_pass, restricted to the cells the centre brick's results depend on.
+#define VRT_FINE_CAP 16
+__global__ __launch_bounds__(256) void k_brick_fine(const uint32_t* __restrict__ padded, int pbx, int pby, const uint32_t* __restrict__ coord,
+                                                    const uint8_t* __restrict__ pool, uint8_t* __restrict__ fine)
+{
+    __shared__ uint8_t A[24 * 24 * 24], B[24 * 24 * 24];
+    const uint32_t b = blockIdx.x;                             // pool index
+    const uint32_t pc = coord[b];                              // index of the brick in the padded grid
+    const int cbx = (int)(pc % (uint32_t)pbx), cby = (int)((pc / (uint32_t)pbx) % (uint32_t)pby), cbz = (int)(pc / ((uint32_t)pbx * (uint32_t)pby));
+    __shared__ uint32_t nb[27];                               // the 3 x 3 x 3 bricks around it: 0 empty, 0xFFFFFFFF outside the volume
+    if (threadIdx.x < 27) {
+        const int dx = (int)threadIdx.x % 3 - 1, dy = ((int)threadIdx.x / 3) % 3 - 1, dz = (int)threadIdx.x / 9 - 1;
+        nb[threadIdx.x] = padded[(size_t)(cbx + dx) + ((size_t)(cby + dy) + (size_t)(cbz + dz) * (size_t)pby) * (size_t)pbx];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 24 * 24 * 24; t += 256) {
+        const int x = t % 24, y = (t / 24) % 24, z = t / 576;
+        const int k = (x >> 3) + (y >> 3) * 3 + (z >> 3) * 9;
+        const uint32_t ptr = nb[k];
+        uint8_t solid;
+        if (ptr == 0xFFFFFFFFu) solid = 1;                     // outside the volume
+        else if (ptr == 0u) solid = 0;
+        else solid = pool[(size_t)(ptr - 1u) * 512u + (size_t)((x & 7) + (y & 7) * 8 + (z & 7) * 64)] != 0 ? 1 : 0;
+        A[t] = solid ? 0 : VRT_FINE_CAP + 1;
+    }
+    __syncthreads();
+    for (int o = 0; o < 8; o++) {
+        const int sx = (o & 1) ? 1 : -1, sy = (o & 2) ? 1 : -1, sz = (o & 4) ? 1 : -1;
+        // pass x: centre columns, every y and z     A -> B
+        for (int t = threadIdx.x; t < 8 * 24 * 24; t += 256) {
+            const int x = 8 + (t & 7), y = (t >> 3) % 24, z = (t >> 3) / 24;
+            const int i = x + y * 24 + z * 576;
+            int best = A[i];
+            for (int k = 1; k < best; k++) {
+                const int q = x + k * sx;
+                const int val = (q < 0 || q >= 24) ? 0 : (int)A[i + k * sx];
+                const int m = val > k ? val : k;
+                best = best < m ? best : m;
+            }
+            B[i] = (uint8_t)best;
+        }
+        __syncthreads();
+        // pass y: centre columns and rows, every z; the results go to the x-columns 0..7 of B, which this pass does not read
+        for (int t = threadIdx.x; t < 8 * 8 * 24; t += 256) {
+            const int x = 8 + (t & 7), y = 8 + ((t >> 3) & 7), z = t >> 6;
+            const int i = x + y * 24 + z * 576;
+            int best = B[i];
+            for (int k = 1; k < best; k++) {
+                const int q = y + k * sy;
+                const int val = (q < 0 || q >= 24) ? 0 : (int)B[i + k * sy * 24];
+                const int m = val > k ? val : k;
+                best = best < m ? best : m;
+            }
+            B[(x - 8) + y * 24 + z * 576] = (uint8_t)best;
+        }
+        __syncthreads();
+        // pass z: the centre brick
+        for (int t = threadIdx.x; t < 512; t += 256) {
+            const int lx = t & 7, ly = (t >> 3) & 7, lz = t >> 6;
+            const int z = 8 + lz;
+            const int i = lx + (8 + ly) * 24 + z * 576;
+            int best = B[i];
+            for (int k = 1; k < best; k++) {
+                const int q = z + k * sz;
+                const int val = (q < 0 || q >= 24) ? 0 : (int)B[i + k * sz * 576];
+                const int m = val > k ? val : k;
+                best = best < m ? best : m;
+            }
+            fine[((size_t)b * 8u + (size_t)o) * 512u + (size_t)t] = (uint8_t)(best > VRT_FINE_CAP ? VRT_FINE_CAP : best);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_brick_grid(const uint32_t* grid, int nbx, int nby, int nbz, uint32_t* padded, uint8_t* occ, hipStream_t s)
+{
+    const size_t n = (size_t)nbx * nby * nbz;
+    hipLaunchKernelGGL(k_brick_grid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, grid, nbx, nby, nbz, padded, occ);
+    return hipGetLastError();
+}
+
+hipError_t launch_brick_fine(const uint32_t* padded, int pbx, int pby, const uint32_t* coord, uint32_t n_bricks, const uint8_t* pool,
+                             uint8_t* fine, hipStream_t s)
+{
+    if (n_bricks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_brick_fine, dim3(n_bricks), dim3(256), 0, s, padded, pbx, pby, coord, pool, fine);
     return hipGetLastError();
 }
 
@@ -783,6 +891,7 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 
 static int effective_traversal(int t, int fast_loop)
 {
+    if (t == VRT_TRAVERSAL_BRICK) return t;
     if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP || t == VRT_TRAVERSAL_DFJ) return t;
     return fast_loop ? VRT_TRAVERSAL_DF_FAST : VRT_TRAVERSAL_DF;        // AUTO / DF
 }
@@ -791,6 +900,7 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal, p.fast_loop);
     if (t == VRT_TRAVERSAL_DF_FAST) return launch_primary_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
+    if (t == VRT_TRAVERSAL_BRICK) return launch_primary_t<VRT_TRAVERSAL_BRICK, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_primary_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_DFJ) return launch_primary_t<VRT_TRAVERSAL_DFJ, false>(p, s);
@@ -802,6 +912,7 @@ hipError_t launch_shade(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal, p.fast_loop);
     if (t == VRT_TRAVERSAL_DF_FAST) return launch_shade_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
+    if (t == VRT_TRAVERSAL_BRICK) return launch_shade_t<VRT_TRAVERSAL_BRICK, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_shade_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_DFJ) return launch_shade_t<VRT_TRAVERSAL_DFJ, false>(p, s);

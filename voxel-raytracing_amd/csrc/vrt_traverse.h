@@ -40,6 +40,7 @@
 #define VRT_TRAVERSAL_DF 4
 #define VRT_TRAVERSAL_DFJ 5
 #endif
+#define VRT_TRAVERSAL_BRICK 6     // brick scenes (vrt_scene_from_bricks): DF over a two-level clearance; chosen by AUTO
 #define VRT_TRAVERSAL_DF_FAST 7   // internal: DF through the hand-written look-up loop (trace_df_fast); chosen by the host
 
 namespace vrt {
@@ -59,6 +60,16 @@ struct VolumeView {
                                 // (field 8), and one byte 0xFF at offset 9 * df_stride, and all of it is addressable with
                                 // 32-bit offsets (trace_df_fast)
     uint32_t        df_pad_;
+    // brick scenes (vrt_scene_from_bricks; vox / occ* / df are null): the volume in 8^3 bricks.  All grids are padded by one
+    // brick on every side (index (bx+1) + ((by+1) + (bz+1) * pby) * pbx), the border counting as outside the volume.
+    const uint32_t* bgrid;      // 0 = empty brick, 0xFFFFFFFF = border (outside the volume), else 1 + index into bpool / bfine
+    const uint8_t*  bcoarse;    // 8 octant fields over the padded grid: 0 = occupied brick or border, else min(16, side in BRICKS of
+                                // the largest cube of empty bricks cornered here and extending towards the octant's signs)
+    uint64_t        bcoarse_stride;
+    const uint8_t*  bpool;      // 512 voxel ids per occupied brick, voxel (x,y,z) of the brick at x + 8y + 64z
+    const uint8_t*  bfine;      // per occupied brick 8 octants x 512 voxels: 0 = solid, else min(16, side of the largest empty cube
+                                // of VOXELS cornered here ...), looking through the brick's 26 neighbours
+    int32_t         pbx, pby;   // padded grid dimensions in x and y
     int32_t W, H, D;
     int32_t n1x, n1y, n1z;
     int32_t n2x, n2y, n2z;
@@ -1104,6 +1115,119 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
     else trace_df_impl<false, STATS, AHEAD>(v, start, dir, maxSteps, r, stats);
 }
 
+// ---- BRICK: the DF march over a sparse volume -------------------------------------------------------------------------
+// Same loop as DF -- the wave agrees on a number of iterations nobody needs a memory test for, runs them with the shader's
+// own fp32 additions, looks again -- with the clearance read from two levels: in an EMPTY brick one byte per brick and
+// octant says how many bricks are clear (the voxel's own clearance follows from where it sits in its brick), in an OCCUPIED
+// brick one byte per voxel and octant (looking through the neighbouring bricks, up to 16 voxels).  Any lower bound of the
+// true clearance gives the same hit (a run only ever skips voxels that are certainly empty), so the result is the dense
+// DF's and the oracle's bit for bit; empty space costs one byte per BRICK in memory and traffic.
+VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_t oct, int sx, int sy, int sz, uint32_t& material)
+{
+    const int bx = (mx >> 3) + 1, by = (my >> 3) + 1, bz = (mz >> 3) + 1;             // (-1 >> 3 = -1: the border brick)
+    const size_t bi = (size_t)bx + ((size_t)by + (size_t)bz * (size_t)v.pby) * (size_t)v.pbx;
+    const uint32_t c = v.bcoarse[(size_t)oct * (size_t)v.bcoarse_stride + bi];
+    const uint32_t lx = (uint32_t)mx & 7u, ly = (uint32_t)my & 7u, lz = (uint32_t)mz & 7u;
+    if (c != 0u) {                                             // an empty brick with c - 1 empty bricks behind it on every axis
+        const uint32_t rx = sx > 0 ? 8u - lx : lx + 1u, ry = sy > 0 ? 8u - ly : ly + 1u, rz = sz > 0 ? 8u - lz : lz + 1u;
+        const uint32_t k = (c - 1u) * 8u + umin3(rx, ry, rz);
+        return k < 63u ? k : 63u;
+    }
+    const uint32_t ptr = v.bgrid[bi];
+    if (ptr + 1u <= 1u) return 0u;                             // the border (0xFFFFFFFF): the ray has left the volume
+    const size_t l = (size_t)lx + (size_t)ly * 8u + (size_t)lz * 64u;
+    const uint32_t f = v.bfine[((size_t)(ptr - 1u) * 8u + (size_t)oct) * 512u + l];
+    if (f == 0u) material = v.bpool[(size_t)(ptr - 1u) * 512u + l];
+    return f;
+}
+
+template <class STATS>
+VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
+{
+    DdaState s;
+    dda_entry(v, start, dir, s);
+    if (wave_all(oob(v, s.mx, s.my, s.mz))) {
+        s.dx = s.dy = s.dz = 0.0f; s.sdx = s.sdy = s.sdz = 0.0f; s.sx = s.sy = s.sz = 0;
+        finish(s, 0u, s.mask, 0u, r);
+        r.dbg0 = 1u; r.dbg1 = 0u;
+        return;
+    }
+    dda_rest(dir, s);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(s.dx), "+v"(s.dy), "+v"(s.dz));
+    uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
+    uint32_t lmask = s.mask;
+#else
+    bool k0 = (s.mask & 1u) != 0u, k1 = (s.mask & 2u) != 0u, k2 = (s.mask & 4u) != 0u;
+#endif
+    uint32_t material = 0, fetches = 0;
+    bool done = oob(v, s.mx, s.my, s.mz);
+    uint32_t clear = 63u;
+    const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
+    const float kInf = u2f(0x7F800000u);
+    const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
+    uint32_t i = 0;
+    for (;;) {
+        if (!done) {
+            if (i >= maxSteps) {
+                done = true; fetches = i;
+#if defined(__HIP_DEVICE_COMPILE__)
+                lmask = lane_bits(kx, ky, kz);
+#endif
+            } else {
+                uint32_t m = 0u;
+                clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m);
+                st_lookup(stats);
+                if (clear == 0u) {                             // solid, or the border: the ray has left the volume
+                    if (oob(v, s.mx, s.my, s.mz)) fetches = i;
+                    else { material = m; fetches = i + 1u; }
+                    done = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    lmask = lane_bits(kx, ky, kz);
+#endif
+                }
+            }
+        }
+        uint32_t vote = done ? VRT_VOTE_DONE : clear;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(vote));
+#endif
+        uint32_t kw = wave_min_vote(vote);
+        if (kw == VRT_VOTE_DONE) break;
+        uint32_t left = maxSteps - i;
+        kw = kw < left ? kw : left;
+        st_jump(stats, kw > 4u ? 2 : 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        {
+            const uint64_t live = __ballot(vote != VRT_VOTE_DONE);
+            float ox, oy, oz;
+            dda_run_live_masks(s, live, kw, kx, ky, kz, ox, oy, oz);
+            s.mx += steps_signed(s.sdx - ox, gx); s.my += steps_signed(s.sdy - oy, gy); s.mz += steps_signed(s.sdz - oz, gz);
+        }
+#else
+        if (!done) {
+            const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
+            for (uint32_t j = 1; j < kw; j++) dda_advance(s);
+            {
+                uint32_t bx = f2u(s.sdx), by = f2u(s.sdy), bz = f2u(s.sdz);
+                uint32_t mn = umin3(bx, by, bz);
+                k0 = bx == mn; k1 = by == mn; k2 = bz == mn;
+                s.sdx = k0 ? s.sdx + s.dx : s.sdx;
+                s.sdy = k1 ? s.sdy + s.dy : s.sdy;
+                s.sdz = k2 ? s.sdz + s.dz : s.sdz;
+            }
+            s.mx += steps_signed(s.sdx - ox, gx); s.my += steps_signed(s.sdy - oy, gy); s.mz += steps_signed(s.sdz - oz, gz);
+        }
+#endif
+        i += kw;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    finish(s, material, lmask, fetches, r);
+#else
+    finish(s, material, (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2), fetches, r);
+#endif
+}
+
 // DENSE: one R8 fetch per iteration.  Straight-line body with a single exit (out of budget, out of bounds or
 // solid), the voxel index maintained incrementally in IDX (uint32_t for volumes below 4 GiB).
 template <class IDX>
@@ -1445,6 +1569,9 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
     if (TRAV == VRT_TRAVERSAL_JUMP) {
         NoStats ns;
         trace_jump(v, o2, o3, start, dir, maxSteps, r, ns);
+    } else if (TRAV == VRT_TRAVERSAL_BRICK) {
+        NoStats ns;
+        trace_brick(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
         trace_df_fast(v, start, dir, maxSteps, r, ns);

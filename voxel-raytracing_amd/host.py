@@ -334,6 +334,27 @@ class VoxelScene:
             s.set_blue_noise(noise)
         return s
 
+    @classmethod
+    def from_bricks(cls, engine: Engine, grid: np.ndarray, pool: np.ndarray, palette: np.ndarray, sky=None, noise=None):
+        """The volume in 8^3 bricks (vrt_scene_from_bricks): grid uint32 [nbz, nby, nbx] (0 = empty, else 1 + index into pool),
+        pool uint8 [n, 8, 8, 8] indexed [z, y, x] within the brick.  Renders like from_dense of the same content."""
+        g = np.ascontiguousarray(grid, dtype=np.uint32)
+        p = np.ascontiguousarray(pool, dtype=np.uint8).reshape(-1, 512)
+        nbz, nby, nbx = g.shape
+        h = C.c_void_p()
+        cls._raise(lib().vrt_scene_from_bricks(engine.ctx, g.ctypes.data_as(C.c_void_p), nbx, nby, nbz,
+                                               p.ctypes.data_as(C.c_void_p) if p.size else None, p.shape[0],
+                                               materials_from_numpy(palette), C.byref(h)))
+        s = cls(engine, skyboxFilename=sky, _handle=h)
+        if noise is not None:
+            s.set_blue_noise(noise)
+        return s
+
+    def memory_bytes(self) -> int:
+        n = C.c_uint64()
+        check(lib().vrt_scene_memory(self._h, C.byref(n)))
+        return int(n.value)
+
     def _update_dims(self):
         d = (C.c_uint32 * 3)()
         check(lib().vrt_scene_info(self._h, d))

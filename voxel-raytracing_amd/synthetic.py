@@ -224,6 +224,67 @@ def sparse_bricks(N: int = 2048, brick: int = 8, fill: float = 0.015, seed: int 
     return np.repeat(np.repeat(np.repeat(cells, brick, axis=0), brick, axis=1), brick, axis=2)
 
 
+def _brick_cells(N: int, brick: int, fill: float, seed: int):
+    """Occupancy and id per brick of sparse_bricks / sparse_brick_scene: (occ bool [nb]^3, ids uint8 [nb]^3)."""
+    nb = N // brick
+    assert nb * brick == N
+    lat = nb // 8 + 2
+    g = rand_unit(seed, lat * lat * lat, 0).reshape(lat, lat, lat).astype(np.float32)
+    t = (np.arange(nb, dtype=np.float32) + 0.5) / 8.0
+    i0 = np.floor(t).astype(np.int64); f = (t - i0).astype(np.float32)
+    def lerp_axis(a, axis):
+        lo = np.take(a, i0, axis=axis); hi = np.take(a, i0 + 1, axis=axis)
+        shape = [1, 1, 1]; shape[axis] = nb
+        w = f.reshape(shape)
+        return lo * (1 - w) + hi * w
+    field = lerp_axis(lerp_axis(lerp_axis(g, 0), 1), 2)
+    field = field + 0.15 * (rand_unit(seed, nb * nb * nb, 1).reshape(nb, nb, nb).astype(np.float32) - 0.5)
+    thr = np.quantile(field, 1.0 - fill)
+    ids = (1 + (rand_u32(seed, nb * nb * nb, 2) % np.uint32(255))).astype(np.uint8).reshape(nb, nb, nb)
+    return field > thr, ids
+
+
+def sparse_brick_scene(N: int = 2048, fill: float = 0.015, seed: int = 5, carve: bool = True):
+    """BASELINE configs[4] (synthetic:sparse2048(seed=5)): an N^3 volume generated BRICK-WISE -- never as a dense array (2048^3
+    is 8 GiB).  Returns (grid uint32 [nbz, nby, nbx], pool uint8 [n, 8, 8, 8]): grid = 0 for an empty brick, else 1 + its index
+    in the pool.  A fraction `fill` of the 8^3 bricks is occupied, clustered by thresholded value noise (as sparse_bricks);
+    carve: each occupied brick is its id where a hash of the voxel's position keeps it (about 70 %), so that surfaces are
+    rough at the voxel scale; carve=False: solid bricks, dense_from_bricks() of it equals sparse_bricks(N, 8, fill, seed)."""
+    occ, ids = _brick_cells(N, 8, fill, seed)
+    nb = N // 8
+    where = np.flatnonzero(occ.reshape(-1))
+    grid = np.zeros(nb * nb * nb, np.uint32)
+    grid[where] = np.arange(1, where.size + 1, dtype=np.uint32)
+    pool = np.empty((where.size, 8, 8, 8), np.uint8)
+    pool[:] = ids.reshape(-1)[where][:, None, None, None]
+    if carve and where.size:
+        v = np.arange(512, dtype=np.uint32)
+        h = hash32(where.astype(np.uint32)[:, None] * np.uint32(512) + v[None, :] + np.uint32((seed * 0x9E3779B1) & 0xFFFFFFFF))
+        keep = (h % np.uint32(10)) < np.uint32(7)
+        pool = np.where(keep.reshape(-1, 8, 8, 8), pool, np.uint8(0))
+    return grid.reshape(nb, nb, nb), pool
+
+
+def bricks_from_dense(vol: np.ndarray):
+    """Dense [z, y, x] volume (dimensions multiples of 8) -> (grid, pool) of vrt_scene_from_bricks."""
+    D, H, W = vol.shape
+    assert D % 8 == 0 and H % 8 == 0 and W % 8 == 0
+    b = vol.reshape(D // 8, 8, H // 8, 8, W // 8, 8).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 8, 8, 8)
+    occ = b.reshape(b.shape[0], -1).any(axis=1)
+    where = np.flatnonzero(occ)
+    grid = np.zeros(b.shape[0], np.uint32)
+    grid[where] = np.arange(1, where.size + 1, dtype=np.uint32)
+    return grid.reshape(D // 8, H // 8, W // 8), np.ascontiguousarray(b[where])
+
+
+def dense_from_bricks(grid: np.ndarray, pool: np.ndarray) -> np.ndarray:
+    nbz, nby, nbx = grid.shape
+    b = np.zeros((grid.size, 8, 8, 8), np.uint8)
+    where = np.flatnonzero(grid.reshape(-1))
+    b[where] = pool[grid.reshape(-1)[where] - 1]
+    return np.ascontiguousarray(b.reshape(nbz, nby, nbx, 8, 8, 8).transpose(0, 3, 1, 4, 2, 5).reshape(nbz * 8, nby * 8, nbx * 8))
+
+
 def default_camera_for(N_x: int, N_y: int, N_z: int):
     """The reference default camera (8,8,-50)/yaw 90/pitch 0 (voxel_renderer.cpp:20) scaled to the volume."""
     return (N_x / 2.0, N_y / 2.0, -0.8 * N_z), 90.0, 0.0
