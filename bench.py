@@ -165,14 +165,15 @@ def single_frame_launch(vrt, engine, renderer, pushes, W, H, S_frames, reps=3):
             "sample": f"{len(pushes)} poses of the step, one vrt_render_geometry call each, device idle between launches"}
 
 
-def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounces, iters, reps=9):
-    """One frame of a secondary-ray configuration at the bench resolution: kernel times from the library's HIP events
-    (median of `reps` isolated frames), ray / step counts from a second render with the count planes attached."""
+def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounces, iters, reps=9, max_steps=512, kernel="k_primary<DF, megakernel>"):
+    """One frame of a secondary-ray configuration: kernel times from the library's HIP events (median of `reps` isolated
+    frames), ray / step counts from a second render with the count planes attached."""
     st = vrt.VoxelRenderSettings(targetResolution=(W, H))
     st.fsrSetttings.enable = False
     st.occlusionSettings.numSamples = ao
     st.traceSettings.shadows = bool(shadows)
     st.traceSettings.maxReflections = bounces
+    st.traceSettings.maxRaySteps = max_steps
     st.denoiserSettings.enable = iters > 0
     st.denoiserSettings.iterations = max(iters, 1)
     geo = vrt.GeometryStage(engine, st, scene)
@@ -195,7 +196,7 @@ def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounc
     g_ms = median(tg)
     b_geo = S + W * H * B_OUT
     out = {"name": name, "ao_samples": ao, "shadows": int(bool(shadows)), "max_bounces": bounces, "denoiser_passes": iters,
-           "geometry_kernel": "k_primary<DF, megakernel>", "geometry_ms": round(g_ms, 5),
+           "resolution": [W, H], "max_steps": max_steps, "geometry_kernel": kernel, "geometry_ms": round(g_ms, 5),
            "rays_total": rays, "dda_steps_total": S, "Mrays_total_per_s": round(rays / (g_ms * 1e-3) / 1e6, 1),
            "geometry_algorithmic_bytes": b_geo, "geometry_frac": round(b_geo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     if iters > 0:
@@ -373,6 +374,23 @@ def main():
                 ("configs[2]: primary + shadow ray, 1 denoiser pass", 0, True, 0, 1),
                 ("configs[2]: primary + shadow ray, 2 denoiser passes", 0, True, 0, 2),
                 ("reference defaults: AO 4 x 64 steps, shadow ray, <= 5 bounces, 2 denoiser passes", 4, True, 5, 2))]
+            # BASELINE configs[4]: the 2048^3 brick scene at 3840x2160 (one GPU's view of it; the 8-GPU split is the same frame
+            # cut into strips) -- the one configuration whose volume does not sit in the caches
+            t_gen = time.perf_counter()
+            grid, pool = vrt.synthetic.sparse_brick_scene(2048, 0.015, seed=5)
+            sc5 = vrt.VoxelScene.from_bricks(engine, grid, pool, pal, sky=sky, noise=noise)
+            pos5, yaw5, pitch5 = vrt.synthetic.default_camera_for(2048, 2048, 2048)
+            cam5 = vrt.CameraController(position=(pos5[0] + 0.3, pos5[1] + 0.2, pos5[2]), yaw=yaw5, pitch=pitch5)
+            push5 = vrt.make_push(cam5, (2048, 2048, 2048), (3840, 2160), frame=17)
+            e5 = extra_config(vrt, torch, engine, sc5, push5, 3840, 2160,
+                              "configs[4]: synthetic:sparse2048(seed=5) brick scene (1.5 % of 8^3 bricks), 3840x2160, max_steps 6144, 4 bounces, AO 4", 4, True, 4, 0,
+                              reps=5, max_steps=6144, kernel="k_primary<BRICK, megakernel>")
+            e5["scene_device_bytes"] = sc5.memory_bytes()
+            e5["scene_bricks"] = int(pool.shape[0])
+            e5["scene_build_s"] = round(time.perf_counter() - t_gen, 2)
+            extra.append(e5)
+            sc5.destroy()
+            del grid, pool
         cpu = None
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is reported at N = 1 only
             from oracle import oracle                          # checker / CPU baseline only
