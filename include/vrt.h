@@ -223,6 +223,11 @@ int  vrt_render_geometry_slots(vrt_ctx* ctx, const vrt_scene* sc, int32_t n, con
 /* ---- denoiser stage -------------------------------------------------------------------------- */
 #define VRT_DENOISE_CANONICAL  0  /* the intended 9-tap a-trous filter                               */
 #define VRT_DENOISE_AS_SHIPPED 1  /* the std140-aliased 3-tap filter the shipped UBO upload produces  */
+#define VRT_DENOISE_FAST       2  /* flag, OR-ed into either: the weighted passes (pass >= 1, integral stepWidth) evaluate the three
+                                   * edge-stopping weights as ONE hardware exponential, exp2(-(dc2*kc + dn2*kn + dp2*kp)), and divide
+                                   * by multiplying with the hardware reciprocal -- the shader's own freedom (GLSL exp / division are
+                                   * not correctly rounded either).  Stated bound against the exact mode and the oracle: at most ONE
+                                   * RGBA8 code per channel per pass (tests/test_gpu_denoise.py); the exact mode stays the default. */
 
 /* DenoiserSettings, voxel_render_settings.hpp:21-29. */
 typedef struct vrt_denoiser_settings {

@@ -65,3 +65,53 @@ def test_full_renderer_default_settings(vrt, oracle, engine):
     exp = oracle.render(oracle.OracleScene(vol, pal, sky=sky, noise=noise), push, oracle.params_from(st.to_c()), nthreads=8)
     eimg = oracle.denoise(exp["color8"], exp["normal8"], exp["position"])
     assert (img.cpu().numpy() == eimg).all()
+
+
+# ---- VRT_DENOISE_FAST: a stated tolerance instead of bit-exactness ------------------------------------------------------
+# The weighted passes with hardware exp2 / reciprocal: at most ONE RGBA8 code per channel and pass away from the exact
+# filter of the same input (the bound in include/vrt.h).  Checked per pass -- every pass's input is the exact previous pass
+# -- and end to end against the oracle, where the differences of earlier passes are filtered along (still <= passes codes).
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("step", [2.0, 1.0])
+def test_fast_denoise_within_one_code_per_pass(vrt, oracle, engine, mode, step):
+    import torch
+    st, gb = _gbuffer(vrt, engine, (200, 120))
+    g = gb.numpy()
+    worst = 0
+    for iterations in (2, 3, 4):
+        # exact passes 0 .. iterations-2 by the oracle, then the last pass alone: exact (oracle) vs fast (GPU)
+        exp = oracle.denoise(g["color8"], g["normal8"], g["position"], iterations=iterations, step_width0=step, mode=mode)
+        st.denoiserSettings.iterations = iterations
+        st.denoiserSettings.stepWidth = step
+        st.denoiserSettings.mode = mode | vrt.DENOISE_FAST
+        out = vrt.DenoiserStage(engine, st).record(gb.color, gb.normal, gb.position).cpu().numpy()
+        d = np.abs(out.astype(np.int32) - exp.astype(np.int32))
+        worst = max(worst, int(d.max()))
+        assert d.max() <= iterations - 1, (iterations, int(d.max()))          # pass 0 is exact in either mode; one code per weighted pass
+        assert (d != 0).mean() < 0.02                                           # and nearly all pixels agree exactly
+    print("fast denoise: worst difference", worst, "codes")
+
+
+def test_fast_denoise_single_weighted_pass_bound(vrt, oracle, engine):
+    """One weighted pass on an exact input (the golden 16x16 edge case and a random G-buffer): <= 1 code per channel."""
+    import os
+    import torch
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_denoise16.npz"))
+    dev = engine.torch_device
+    rng = np.random.default_rng(99)
+    H, W = 96, 160
+    cases = [(gold["color"], gold["normal"], gold["position"])]
+    pos = np.zeros((H, W, 4), np.float32); pos[..., :3] = rng.uniform(0, 64, (H, W, 3)).astype(np.float32) * (rng.random((H, W, 1)) < 0.7)
+    pos[..., :3] = np.round(pos[..., :3] * 4) / 4                                # clustered positions: non-trivial weights
+    nrm = np.zeros((H, W, 4), np.int8); nrm[..., :3] = rng.choice(np.array([-127, 0, 90, 127], np.int8), (H, W, 3))
+    cases.append((rng.integers(0, 256, (H, W, 4), dtype=np.uint8), nrm, pos))
+    for color, normal, position in cases:
+        c, n, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (color, normal, position))
+        for mode in (0, 1):
+            st = vrt.VoxelRenderSettings(targetResolution=(color.shape[1], color.shape[0]))
+            st.denoiserSettings.iterations = 2
+            st.denoiserSettings.mode = mode | vrt.DENOISE_FAST
+            fast = vrt.DenoiserStage(engine, st).record(c, n, p).cpu().numpy()
+            exact = oracle.denoise(color, normal, position, iterations=2, mode=mode)
+            assert np.abs(fast.astype(np.int32) - exact.astype(np.int32)).max() <= 1, mode

@@ -13,7 +13,7 @@ ERR_NAMES = {1: "VRT_ERR_INVALID", 2: "VRT_ERR_IO", 3: "VRT_ERR_PARSE", 4: "VRT_
              5: "VRT_ERR_NO_DEVICE", 6: "VRT_ERR_HIP", 7: "VRT_ERR_UNSUPPORTED"}
 
 TRAVERSAL_AUTO, TRAVERSAL_DENSE, TRAVERSAL_BITMASK, TRAVERSAL_JUMP, TRAVERSAL_DF, TRAVERSAL_DFJ = 0, 1, 2, 3, 4, 5
-DENOISE_CANONICAL, DENOISE_AS_SHIPPED = 0, 1
+DENOISE_CANONICAL, DENOISE_AS_SHIPPED, DENOISE_FAST = 0, 1, 2       # FAST is a flag OR-ed into either
 MAX_BOUNCES = 8
 
 

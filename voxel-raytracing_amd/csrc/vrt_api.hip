@@ -863,6 +863,7 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
 {
     if (!c || !ds || !color_in || !normal8 || !position || !result) return fail(VRT_ERR_INVALID, "vrt_denoise: NULL argument");
     if (ds->iterations < 0 || ds->iterations > 10) return fail(VRT_ERR_INVALID, "vrt_denoise: iterations must be in 0..10 (MAX_DENOISER_PASSES)");
+    if (ds->mode < 0 || ds->mode > 3) return fail(VRT_ERR_INVALID, "vrt_denoise: mode must be VRT_DENOISE_CANONICAL or _AS_SHIPPED, optionally | VRT_DENOISE_FAST");
     if (ds->iterations > 0 && !target0) return fail(VRT_ERR_INVALID, "vrt_denoise: target0 is NULL");
     if (ds->iterations > 1 && !target1) return fail(VRT_ERR_INVALID, "vrt_denoise: target1 is NULL");
     if (!(ds->phi_color0 > 0.0f) || !(ds->phi_normal0 > 0.0f) || !(ds->phi_pos0 > 0.0f))
@@ -890,6 +891,10 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
         p.phi_normal = inv * ds->phi_normal0;
         p.phi_pos = inv * ds->phi_pos0;
         p.step_width = (float)i * ds->step_width + 1.0f;
+        {
+            const float log2e = 1.44269504088896341f;
+            p.kc = log2e / p.phi_color; p.kp = log2e / p.phi_pos; p.kn = log2e / (p.phi_normal * (p.step_width * p.step_width));   // pass 0: all 0
+        }
         p.color_in = last; p.color_out = targets[ping];
         int ext = 0;
         if (p.sh.nranks > 1) for (int j = i + 1; j < ds->iterations; j++) ext += tap_reach(ds, j);

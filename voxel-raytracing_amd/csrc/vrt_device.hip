@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
     int py = strip_row(P.sh, P.extend, r, P.H);
     if (py < 0 || px >= P.W) return;
 
-    const bool shipped = P.mode == VRT_DENOISE_AS_SHIPPED;
+    const bool shipped = (P.mode & 1) == VRT_DENOISE_AS_SHIPPED;
     const int ntaps = shipped ? 3 : 9;
     float sw = P.step_width;
     float sw2 = sw * sw;
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
 // R = stepWidth pixels are fetched, decoded ONCE and parked in LDS as three float4 planes (48 B per pixel), so each
 // pixel's guides are read from HBM/L2 once per pass instead of once per tap that lands on it (9x), and the 8-bit
 // decodes are not repeated per tap.  Same arithmetic on the same decoded values as k_denoise.
-template <bool PHI_INF, bool SHIPPED>
+template <bool PHI_INF, bool SHIPPED, bool FAST = false>
 __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
@@ -1135,7 +1135,15 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
         const float4 oc = lc[ci];
         const float o_c[4] = {oc.x, oc.y, oc.z, oc.w};
         float w = 1.0f;
-        if (!PHI_INF) {
+        if (!PHI_INF && FAST) {
+            // the product of the three weights as one exponential (each argument is <= 0, so no factor exceeds 1 and the
+            // shader's min(., 1) has nothing to do): three multiply-adds and one v_exp_f32 instead of three divisions and
+            // three polynomial exponentials
+            const float4 op = lp[ci], on = ln[ci];
+            const float o_p[4] = {op.x, op.y, op.z, op.w}, o_n[4] = {on.x, on.y, on.z, on.w};
+            const float e = __builtin_fmaf(dist2_4(s_p, o_p), P.kp, __builtin_fmaf(dist2_4(s_c, o_c), P.kc, fmaxf(dist2_4(s_n, o_n), 0.0f) * P.kn));
+            w = __builtin_amdgcn_exp2f(-e);
+        } else if (!PHI_INF) {
             const float4 op = lp[ci];
             const float o_p[4] = {op.x, op.y, op.z, op.w};
             float pw = edge_weight(dist2_4(s_p, o_p), P.phi_pos);
@@ -1168,11 +1176,92 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
             q[k] = __builtin_fmaf(__builtin_fmaf(-total, q1, sum[k]), r, q1);
         }
         out.x = unorm8(q[0]); out.y = unorm8(q[1]); out.z = unorm8(q[2]); out.w = unorm8(q[3]);
+    } else if (FAST) {
+        const float r = __builtin_amdgcn_rcpf(total);
+        out.x = unorm8(sum[0] * r); out.y = unorm8(sum[1] * r); out.z = unorm8(sum[2] * r); out.w = unorm8(sum[3] * r);
     } else {
         out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
         out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
     }
     reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
+}
+
+// VRT_DENOISE_FAST on a whole frame (one rank, integral stepWidth, a weighted pass): a workgroup owns 64 x TH pixels, four rows
+// at a time per wave, so that the guides of the tile + halo are fetched and decoded once for TH rows instead of four (a
+// halo of R = 3 rows above and below makes a 4-row tile read 2.5x its own rows, a 16-row tile 1.4x); the weights are one
+// hardware exponential per tap (see VRT_DENOISE_FAST in vrt.h).
+typedef float v2f __attribute__((ext_vector_type(2)));
+// |a - b|^2 of two float4 in packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: two lanes' worth per instruction);
+// fused and re-associated -- the fast mode states a tolerance, not a rounding
+__device__ __forceinline__ float dist2_pk(const float4& a, const float4& b)
+{
+    const v2f d0 = (v2f){a.x, a.y} - (v2f){b.x, b.y}, d1 = (v2f){a.z, a.w} - (v2f){b.z, b.w};
+    const v2f q = __builtin_elementwise_fma(d1, d1, d0 * d0);
+    return q.x + q.y;
+}
+
+template <bool SHIPPED, int TH>
+__global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int R)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
+    const int RW = 64 + 2 * R, RH = TH + 2 * R, NP = RW * RH;
+    float4* lc = lds_g; float4* ln = lds_g + NP; float4* lp = lds_g + 2 * NP;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TH;
+    {
+        int cy = (int)threadIdx.x / RW, cx = (int)threadIdx.x - cy * RW;       // (RW >= 66: cy is 0..3)
+        const int dy = 256 / RW, dx = 256 - dy * RW;
+        const float r255 = 1.0f / 255.0f, r127 = 1.0f / 127.0f;
+        for (int t = (int)threadIdx.x; t < NP; t += 256) {
+            int x = x0 - R + cx, y = y0 - R + cy;
+            x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+            y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+            const size_t i = (size_t)y * (size_t)P.W + (size_t)x;
+            const uchar4 c = reinterpret_cast<const uchar4*>(P.color_in)[i];
+            const char4 n = reinterpret_cast<const char4*>(P.normal)[i];
+            lc[t] = make_float4((float)c.x * r255, (float)c.y * r255, (float)c.z * r255, (float)c.w * r255);
+            ln[t] = make_float4(fmaxf((float)n.x * r127, -1.0f), fmaxf((float)n.y * r127, -1.0f), fmaxf((float)n.z * r127, -1.0f), fmaxf((float)n.w * r127, -1.0f));
+            lp[t] = reinterpret_cast<const float4*>(P.position)[i];
+            cx += dx; cy += dy;
+            if (cx >= RW) { cx -= RW; cy++; }
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, px = x0 + lx;
+    if (px >= P.W) return;
+    constexpr int ntaps = SHIPPED ? 3 : 9;
+    const int rowoff = R * RW;
+    for (int ly = (int)(threadIdx.x >> 6); ly < TH; ly += 4) {
+        const int py = y0 + ly;
+        if (py >= P.H) break;
+        const int c0 = (ly + R) * RW + (lx + R);
+        const float4 sc = lc[c0], sn = ln[c0], sp = lp[c0];
+        v2f s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < ntaps; i++) {
+            int tx, ty; float kern;
+            if (SHIPPED) {
+                tx = i == 0 ? -1 : (i == 1 ? 1 : 0); ty = i == 2 ? 0 : -1;
+                kern = i == 1 ? kGauss0 : kGauss2;
+            } else {
+                tx = i % 3 - 1; ty = i / 3 - 1;
+                const int r2 = tx * tx + ty * ty;
+                kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2);
+            }
+            const int ci = c0 + ty * rowoff + tx * R;
+            const float4 oc = lc[ci], op = lp[ci], on = ln[ci];
+            const float e = __builtin_fmaf(dist2_pk(sp, op), P.kp, __builtin_fmaf(dist2_pk(sc, oc), P.kc, dist2_pk(sn, on) * P.kn));
+            const float wk = __builtin_amdgcn_exp2f(-e) * kern;
+            const v2f w2 = {wk, wk};
+            s01 = __builtin_elementwise_fma((v2f){oc.x, oc.y}, w2, s01);
+            s23 = __builtin_elementwise_fma((v2f){oc.z, oc.w}, w2, s23);
+            total += wk;
+        }
+        const float r = __builtin_amdgcn_rcpf(total);
+        uchar4 out;
+        out.x = unorm8(s01.x * r); out.y = unorm8(s01.y * r); out.z = unorm8(s23.x * r); out.w = unorm8(s23.y * r);
+        reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
+    }
 }
 
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
@@ -1189,8 +1278,22 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
     if (tiled) {
         size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * (inf ? 16 : 48);   // pass 0 stages the colour plane only
-        const bool shipped = p.mode == VRT_DENOISE_AS_SHIPPED;
-        if (inf) { if (shipped) hipLaunchKernelGGL((k_denoise_lds<true, true>), grid, block, lds, s, p, R);
+        const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
+        if (!inf && (p.mode & VRT_DENOISE_FAST) && p.sh.nranks == 1 && p.extend == 0) {
+            const char* e = getenv("VRT_DENOISE_TH");                        // development switch: tile height 8 / 16
+            const int th = (e && e[0] == '1') ? 16 : 8;
+            dim3 g2((unsigned)((p.W + 63) / 64), (unsigned)((p.H + th - 1) / th));
+            const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(th + 2 * R) * 48;
+            if (th == 8) { if (shipped) hipLaunchKernelGGL((k_denoise_fast<true, 8>), g2, block, l2, s, p, R);
+                           else         hipLaunchKernelGGL((k_denoise_fast<false, 8>), g2, block, l2, s, p, R); }
+            else         { if (shipped) hipLaunchKernelGGL((k_denoise_fast<true, 16>), g2, block, l2, s, p, R);
+                           else         hipLaunchKernelGGL((k_denoise_fast<false, 16>), g2, block, l2, s, p, R); }
+        }
+        else if (!inf && (p.mode & VRT_DENOISE_FAST)) {
+            if (shipped) hipLaunchKernelGGL((k_denoise_lds<false, true, true>), grid, block, lds, s, p, R);
+            else         hipLaunchKernelGGL((k_denoise_lds<false, false, true>), grid, block, lds, s, p, R);
+        }
+        else if (inf) { if (shipped) hipLaunchKernelGGL((k_denoise_lds<true, true>), grid, block, lds, s, p, R);
                    else         hipLaunchKernelGGL((k_denoise_lds<true, false>), grid, block, lds, s, p, R); }
         else     { if (shipped) hipLaunchKernelGGL((k_denoise_lds<false, true>), grid, block, lds, s, p, R);
                    else         hipLaunchKernelGGL((k_denoise_lds<false, false>), grid, block, lds, s, p, R); }

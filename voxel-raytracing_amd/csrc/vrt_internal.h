@@ -185,6 +185,7 @@ struct DenoiseParams {
     int32_t W, H;
     float phi_color, phi_normal, phi_pos, step_width;
     int32_t mode;
+    float   kc, kn, kp;        // VRT_DENOISE_FAST: log2(e) / phi per channel (kn also / stepWidth^2)
     int32_t extend;            // rows beyond each owned strip that this pass must also produce
     ShardMap sh;
 };
