@@ -279,6 +279,25 @@ int  vrt_unpack_halo(vrt_ctx* ctx, const void* packed, void* full, int32_t W, in
                      int32_t bytes_per_px, const vrt_shard* shard, int32_t halo, int32_t dir);
 size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bytes_per_px, const vrt_shard* shard, int32_t halo);
 
+/* ---- the collective itself, for hosts without torch.distributed (no reference analogue; BASELINE north_star: "C++ host code
+ * ... RCCL gather over xGMI") ---------------------------------------------------------------------------------------------
+ * RCCL (librccl.so, found with dlopen at first use: the library the process already has -- torch's own copy in a Python
+ * process -- or /opt/rocm's) behind plain C: one communicator rank per vrt_ctx.  Two ways to build the ranks:
+ *   one process per GPU:        rank 0 calls vrt_comm_unique_id, hands the 128 bytes to the others out of band (a file, MPI,
+ *                               a socket), every rank calls vrt_comm_init_rank;
+ *   one process, several GPUs:  vrt_comm_init_all over the contexts (the C++ App: `vrt_app --devices 0,1,...`); calls that
+ *                               belong to different ranks of one step are then wrapped in vrt_group_start / vrt_group_end.
+ * vrt_gather_strips: every rank's `bytes` at `send` arrive at `recv + r * bytes` on `root` (the packed strips of vrt_pack_rows:
+ * root unpacks them with vrt_unpack_rows and rank r's vrt_shard).  Enqueued on the context's stream; device pointers. */
+typedef struct vrt_comm vrt_comm;
+int  vrt_comm_unique_id(uint8_t id[128]);
+int  vrt_comm_init_rank(vrt_ctx* ctx, int32_t nranks, int32_t rank, const uint8_t id[128], vrt_comm** out);
+int  vrt_comm_init_all(int32_t n, vrt_ctx* const* ctxs, vrt_comm** out /* n handles */);
+void vrt_comm_destroy(vrt_comm* comm);
+int  vrt_group_start(void);
+int  vrt_group_end(void);
+int  vrt_gather_strips(vrt_ctx* ctx, vrt_comm* comm, int32_t root, const void* send, void* recv, size_t bytes);
+
 /* ---- presentation / temporal helpers ----------------------------------- */
 /* Replaces BlitStage::record + shader/blit.frag:14-22 (source/voxels/stages/blit_stage.cpp:41-75): the RGBA8 source
  * is centre-cropped to the target's aspect ratio and resampled with a linear, clamp-to-edge sampler

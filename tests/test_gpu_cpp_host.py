@@ -94,3 +94,58 @@ def test_cpp_app_temporal_window(vrt, oracle, tmp_path):
     assert (got == exp).all(), int((got != exp).sum())
     img = vrt.load_image(str(tmp_path / "o.png"))
     assert img.shape[:2] == (100, 100)
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("devices", ["0", "0,1"])
+def test_cpp_app_devices_rccl_gather(vrt, oracle, tmp_path, devices):
+    """vrt_app --devices a,b,...: one process, one context + scene per GPU, 16-row strips, the C-ABI's RCCL gather
+    (vrt_comm_init_all / vrt_gather_strips) to the first device, denoiser on the assembled frame: the image must equal the
+    single-device path's and the oracle's.  "0" runs the whole multi-device code path on the one GPU every box has (a
+    one-rank communicator); "0,1" needs two."""
+    n = len(devices.split(","))
+    if _gpu_count() < n:
+        pytest.skip(f"needs {n} GPUs")
+    vol = vrt.synthetic.floating_cubes(48, seed=6, count=60)
+    pal = metallic_palette(vrt)
+    sky, noise = vrt.synthetic.sky_gradient(64, 32), vrt.synthetic.blue_noise_standin(64)
+    dense = tmp_path / "scene.vrtd"
+    _write_dense(dense, vol, pal, sky, noise)
+    raw, ref, pushf = tmp_path / "multi.rgba", tmp_path / "single.rgba", tmp_path / "push.bin"
+    common = ["--dense", str(dense), "--width", "200", "--height", "150", "--no-fsr", "--pos", "24.3", "24.2", "-40"]
+    r = subprocess.run([APP] + common + ["--devices", devices, "--raw", str(raw)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert "RCCL gather" in r.stdout
+    r = subprocess.run([APP] + common + ["--raw", str(ref), "--dump-push", str(pushf)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(raw.read_bytes(), np.uint8).reshape(150, 200, 4)
+    single = np.frombuffer(ref.read_bytes(), np.uint8).reshape(150, 200, 4)
+    assert (got == single).all(), int((got != single).sum())
+    push = oracle.Push.from_buffer_copy(pushf.read_bytes())
+    st = vrt.VoxelRenderSettings(targetResolution=(200, 150)); st.fsrSetttings.enable = False
+    exp = oracle.render(oracle.OracleScene(vol, pal, sky=sky, noise=noise), push, oracle.params_from(st.to_c()), nthreads=8)
+    assert (got == oracle.denoise(exp["color8"], exp["normal8"], exp["position"])).all()
+
+
+def test_capi_gather_one_rank(vrt, engine):
+    """The collective entry points through ctypes on one GPU: a one-rank communicator, gather = copy."""
+    import torch
+    lib = vrt.lib()
+    ctxs = (C.c_void_p * 1)(engine.ctx)
+    comm = (C.c_void_p * 1)()
+    vrt._capi.check(lib.vrt_comm_init_all(1, ctxs, comm))
+    src = torch.arange(4096, dtype=torch.uint8, device=engine.torch_device)
+    dst = torch.zeros_like(src)
+    vrt._capi.check(lib.vrt_group_start())
+    vrt._capi.check(lib.vrt_gather_strips(engine.ctx, comm[0], 0, src.data_ptr(), dst.data_ptr(), src.numel()))
+    vrt._capi.check(lib.vrt_group_end())
+    engine.synchronize()
+    assert (dst == src).all()
+    uid = (C.c_uint8 * 128)()
+    vrt._capi.check(lib.vrt_comm_unique_id(uid))
+    assert any(uid)
+    lib.vrt_comm_destroy(comm[0])

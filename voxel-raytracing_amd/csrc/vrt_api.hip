@@ -1057,6 +1057,140 @@ int vrt_jitter_offset(int32_t index, int32_t phase_count, float* jitter_x, float
     return VRT_OK;
 }
 
+// ---- RCCL behind the C-ABI ---------------------------------------------------------------------------
+
+} // extern "C"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct vrt_comm { ncclComm_t comm = nullptr; int rank = 0, nranks = 1; };
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// librccl of the process: a copy that is already loaded wins (dlopen by soname returns it), else /opt/rocm's
+Rccl* rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+#define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
+            SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
+            SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+            SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv) {
+                dlclose(r.lib); r.lib = nullptr;
+            }
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+
+int nccl_fail(const char* what, ncclResult_t e)
+{
+    Rccl* r = rccl();
+    return fail(VRT_ERR_HIP, std::string(what) + ": " + ((r && r->GetErrorString) ? r->GetErrorString(e) : "RCCL error"));
+}
+
+#define RCCL_OR_FAIL(r) Rccl* r = rccl(); if (!r) return fail(VRT_ERR_UNSUPPORTED, "librccl.so could not be loaded")
+
+} // namespace
+
+extern "C" {
+
+int vrt_comm_unique_id(uint8_t id[128])
+{
+    if (!id) return fail(VRT_ERR_INVALID, "vrt_comm_unique_id: NULL argument");
+    RCCL_OR_FAIL(r);
+    ncclUniqueId u;
+    ncclResult_t e = r->GetUniqueId(&u);
+    if (e != ncclSuccess) return nccl_fail("ncclGetUniqueId", e);
+    static_assert(sizeof u == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id, &u, 128);
+    return VRT_OK;
+}
+
+int vrt_comm_init_rank(vrt_ctx* c, int32_t nranks, int32_t rank, const uint8_t id[128], vrt_comm** out)
+{
+    if (!c || !id || !out) return fail(VRT_ERR_INVALID, "vrt_comm_init_rank: NULL argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(VRT_ERR_INVALID, "vrt_comm_init_rank: need 0 <= rank < nranks");
+    RCCL_OR_FAIL(r);
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId u; memcpy(&u, id, 128);
+    vrt_comm* k = new vrt_comm(); k->rank = rank; k->nranks = nranks;
+    ncclResult_t e = r->CommInitRank(&k->comm, nranks, u, rank);
+    if (e != ncclSuccess) { delete k; return nccl_fail("ncclCommInitRank", e); }
+    *out = k;
+    return VRT_OK;
+}
+
+int vrt_comm_init_all(int32_t n, vrt_ctx* const* ctxs, vrt_comm** out)
+{
+    if (!ctxs || !out || n < 1) return fail(VRT_ERR_INVALID, "vrt_comm_init_all: bad argument");
+    RCCL_OR_FAIL(r);
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; i++) { if (!ctxs[i]) return fail(VRT_ERR_INVALID, "vrt_comm_init_all: NULL context"); devs[(size_t)i] = ctxs[i]->device; }
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++)
+        if (devs[(size_t)i] == devs[(size_t)j]) return fail(VRT_ERR_INVALID, "vrt_comm_init_all: two ranks on one device (RCCL wants one GPU per rank)");
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    ncclResult_t e = r->CommInitAll(comms.data(), n, devs.data());
+    if (e != ncclSuccess) return nccl_fail("ncclCommInitAll", e);
+    for (int i = 0; i < n; i++) { vrt_comm* k = new vrt_comm(); k->comm = comms[(size_t)i]; k->rank = i; k->nranks = n; out[i] = k; }
+    return VRT_OK;
+}
+
+void vrt_comm_destroy(vrt_comm* k)
+{
+    if (!k) return;
+    Rccl* r = rccl();
+    if (r && k->comm) r->CommDestroy(k->comm);
+    delete k;
+}
+
+int vrt_group_start(void) { RCCL_OR_FAIL(r); ncclResult_t e = r->GroupStart(); return e == ncclSuccess ? VRT_OK : nccl_fail("ncclGroupStart", e); }
+int vrt_group_end(void)   { RCCL_OR_FAIL(r); ncclResult_t e = r->GroupEnd();   return e == ncclSuccess ? VRT_OK : nccl_fail("ncclGroupEnd", e); }
+
+int vrt_gather_strips(vrt_ctx* c, vrt_comm* k, int32_t root, const void* send, void* recv, size_t bytes)
+{
+    if (!c || !k || !send) return fail(VRT_ERR_INVALID, "vrt_gather_strips: NULL argument");
+    if (root < 0 || root >= k->nranks) return fail(VRT_ERR_INVALID, "vrt_gather_strips: root out of range");
+    if (k->rank == root && !recv) return fail(VRT_ERR_INVALID, "vrt_gather_strips: the root needs a receive buffer");
+    RCCL_OR_FAIL(r);
+    HIPCHK(hipSetDevice(c->device));
+    // a gather as grouped point-to-point operations: every rank's one send travels its own xGMI link to the root, whose
+    // nranks receives proceed in parallel
+    ncclResult_t e = r->GroupStart();
+    if (e != ncclSuccess) return nccl_fail("ncclGroupStart", e);
+    if (k->rank == root)
+        for (int src = 0; src < k->nranks && e == ncclSuccess; src++)
+            e = r->Recv((uint8_t*)recv + (size_t)src * bytes, bytes, ncclUint8, src, k->comm, c->stream);
+    if (e == ncclSuccess) e = r->Send(send, bytes, ncclUint8, root, k->comm, c->stream);
+    ncclResult_t e2 = r->GroupEnd();
+    if (e != ncclSuccess) return nccl_fail("ncclSend / ncclRecv", e);
+    if (e2 != ncclSuccess) return nccl_fail("ncclGroupEnd", e2);
+    return VRT_OK;
+}
+
 // ---- instrumentation -------------------------------------------------------------------------------
 
 int vrt_last_timings(vrt_ctx* c, float* primary_ms, float* geometry_ms, float* denoise_ms)

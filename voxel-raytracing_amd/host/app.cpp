@@ -48,6 +48,7 @@ int run(int argc, char** argv)
         std::string vox, dense, out, raw, dumpPush, sky, noise, png;
         auto settings = std::make_shared<VoxelRenderSettings>();
         vec3 pos{8, 8, -50}; float yaw = 90, pitch = 0; bool havePos = false; int device = 0;
+        std::vector<int> devices;                                          // --devices a,b,...: one process drives several GPUs
         int frames = 1; uint32_t windowW = 0, windowH = 0; float flyForward = 0, flyStrafe = 0, flyMouseX = 0; bool temporal = false;
         for (int i = 1; i < argc; i++) {
             std::string a = argv[i];
@@ -67,11 +68,34 @@ int run(int argc, char** argv)
             else if (a == "--no-shadows") settings->traceSettings.shadows = false;
             else if (a == "--primary-only") { settings->occlusionSettings.numSamples = 0; settings->traceSettings.shadows = false; settings->traceSettings.maxReflections = 0; }
             else if (a == "--device") device = std::stoi(next());
+            else if (a == "--devices") { std::string l = next(); size_t p0 = 0; while (p0 <= l.size()) { size_t c = l.find(',', p0); if (c == std::string::npos) c = l.size(); if (c > p0) devices.push_back(std::stoi(l.substr(p0, c - p0))); p0 = c + 1; } }
             else if (a == "--frames") frames = std::max(1, std::stoi(next()));                 // frames to run (update + render each)
             else if (a == "--temporal") temporal = true;                                       // accumulate jittered frames + upscale
             else if (a == "--window") { windowW = (uint32_t)std::stoul(next()); windowH = (uint32_t)std::stoul(next()); }
             else if (a == "--fly") { flyForward = std::stof(next()); flyStrafe = std::stof(next()); flyMouseX = std::stof(next()); }
             else throw std::runtime_error("unknown argument " + a);
+        }
+        if (!devices.empty()) {
+            // screen strips over the listed GPUs, RCCL gather to the first one (ShardedRenderer); the scene is loaded on each
+            std::vector<std::shared_ptr<Engine>> engines; std::vector<std::shared_ptr<VoxelScene>> scenes;
+            for (int d : devices) {
+                auto e = std::make_shared<Engine>(d);
+                std::shared_ptr<VoxelScene> sc = !dense.empty() ? loadDense(e, dense) : std::make_shared<VoxelScene>(e, vox.empty() ? settings->voxPath : vox);
+                if (!sky.empty()) sc->setSkybox(sky);
+                if (!noise.empty()) sc->setBlueNoise(noise);
+                engines.push_back(e); scenes.push_back(sc);
+            }
+            VoxelRenderer cameraOnly(engines[0], settings, scenes[0]);                         // push constants as the single-GPU path builds them
+            if (!havePos) pos = {scenes[0]->width / 2.0f, scenes[0]->height / 2.0f, -0.8f * scenes[0]->depth};
+            cameraOnly.camera().position = pos; cameraOnly.camera().yaw = yaw; cameraOnly.camera().pitch = pitch;
+            cameraOnly.camera().updateDirectionVectors();
+            ShardedRenderer sharded(engines, settings, scenes);
+            uint32_t res[2] = {0, 0};
+            std::vector<uint8_t> img = sharded.render(cameraOnly.pushConstants(), &res[0], &res[1]);
+            if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)img.data(), (std::streamsize)img.size());
+            if (!png.empty()) check(vrt_image_write_png(png.c_str(), img.data(), res[0], res[1]));
+            std::printf("rendered %ux%u on %zu device(s), RCCL gather\n", res[0], res[1], devices.size());
+            return EXIT_SUCCESS;
         }
         auto engine = std::make_shared<Engine>(device);
         std::shared_ptr<VoxelScene> scene;

@@ -334,4 +334,78 @@ private:
     float _time = 0;
 };
 
+// ---- one process, several GPUs (no reference analogue; BASELINE north_star) -----------------------------------------------
+// The frame cut into 16-row strips, strip s traced by device s % N (every device holds the whole scene), the three planes the
+// rest of the frame graph reads -- colour, normal, position -- gathered to device 0 through RCCL (vrt_gather_strips, one
+// grouped gather per plane), assembled there, and the denoiser run on the assembled frame.  (The Python host also shards
+// the denoiser, with a ring exchange of halo rows: voxel-raytracing_amd/distributed.py.)
+class ShardedRenderer {
+public:
+    ShardedRenderer(const std::vector<std::shared_ptr<Engine>>& engines, const std::shared_ptr<VoxelRenderSettings>& settings,
+                    const std::vector<std::shared_ptr<VoxelScene>>& scenes, int stripRows = 16)
+        : engines(engines), settings(settings), scenes(scenes), stripRows(stripRows), comms(engines.size(), nullptr)
+    {
+        if (engines.empty() || engines.size() != scenes.size()) throw std::runtime_error("ShardedRenderer: one scene per engine");
+        std::vector<vrt_ctx*> ctxs;
+        for (auto& e : engines) ctxs.push_back(e->ctx);
+        check(vrt_comm_init_all((int32_t)ctxs.size(), ctxs.data(), comms.data()));
+        for (size_t i = 0; i < engines.size(); i++) stages.push_back(std::make_unique<GeometryStage>(engines[i], settings, scenes[i]));
+        denoiser = std::make_unique<DenoiserStage>(engines[0], settings);
+    }
+    ~ShardedRenderer() { for (vrt_comm* c : comms) vrt_comm_destroy(c); }
+    ShardedRenderer(const ShardedRenderer&) = delete; ShardedRenderer& operator=(const ShardedRenderer&) = delete;
+
+    std::vector<uint8_t> render(const vrt_push& push, uint32_t* outW = nullptr, uint32_t* outH = nullptr)
+    {
+        const int n = (int)engines.size();
+        auto res = settings->renderResolution();
+        const int32_t W = (int32_t)res[0], H = (int32_t)res[1];
+        std::vector<GeometryBuffer> gbs;
+        std::vector<vrt_shard> shards((size_t)n);
+        for (int r = 0; r < n; r++) {                                   // every device traces its strips (asynchronously)
+            shards[(size_t)r] = vrt_shard{r, n, stripRows};
+            gbs.push_back(stages[(size_t)r]->record(push, n > 1 ? &shards[(size_t)r] : nullptr));
+        }
+        {                                                               // (one device: a one-rank communicator, the same path)
+            const size_t rows = (size_t)vrt_shard_rows(H, &shards[0]);
+            if (!full.color || full.width != res[0] || full.height != res[1]) {
+                size_t px = (size_t)W * H;
+                full.color = std::make_shared<DeviceBuffer<uint8_t>>(engines[0], px * 4); full.normal = std::make_shared<DeviceBuffer<int8_t>>(engines[0], px * 4);
+                full.position = std::make_shared<DeviceBuffer<float>>(engines[0], px * 4);
+                full.width = res[0]; full.height = res[1];
+                packed.clear(); gathered.reset();
+                for (int r = 0; r < n; r++) packed.push_back(std::make_shared<DeviceBuffer<uint8_t>>(engines[(size_t)r], rows * (size_t)W * 16));
+                gathered = std::make_shared<DeviceBuffer<uint8_t>>(engines[0], (size_t)n * rows * (size_t)W * 16);
+            }
+            for (int plane = 0; plane < 3; plane++) {
+                const int bpp = plane == 2 ? 16 : 4;
+                const size_t bytes = rows * (size_t)W * (size_t)bpp;
+                for (int r = 0; r < n; r++) {
+                    const void* src = plane == 0 ? (const void*)gbs[(size_t)r].color->ptr : (plane == 1 ? (const void*)gbs[(size_t)r].normal->ptr : (const void*)gbs[(size_t)r].position->ptr);
+                    check(vrt_pack_rows(engines[(size_t)r]->ctx, src, packed[(size_t)r]->ptr, W, H, bpp, &shards[(size_t)r]));
+                }
+                check(vrt_group_start());                               // the n ranks of this process: one grouped gather
+                for (int r = 0; r < n; r++)
+                    check(vrt_gather_strips(engines[(size_t)r]->ctx, comms[(size_t)r], 0, packed[(size_t)r]->ptr, r == 0 ? gathered->ptr : nullptr, bytes));
+                check(vrt_group_end());
+                void* dst = plane == 0 ? (void*)full.color->ptr : (plane == 1 ? (void*)full.normal->ptr : (void*)full.position->ptr);
+                for (int r = 0; r < n; r++)
+                    check(vrt_unpack_rows(engines[0]->ctx, gathered->ptr + (size_t)r * bytes, dst, W, H, bpp, &shards[(size_t)r]));
+                for (int r = 1; r < n; r++) engines[(size_t)r]->waitIdle();   // the send buffers are reused by the next plane
+                engines[0]->waitIdle();
+            }
+        }
+        const uint8_t* img = settings->denoiserSettings.enable ? denoiser->record(full) : full.color->ptr;
+        std::vector<uint8_t> host((size_t)W * H * 4);
+        check(vrt_memcpy_d2h(engines[0]->ctx, host.data(), img, host.size()));
+        if (outW) *outW = res[0];
+        if (outH) *outH = res[1];
+        return host;
+    }
+private:
+    std::vector<std::shared_ptr<Engine>> engines; std::shared_ptr<VoxelRenderSettings> settings; std::vector<std::shared_ptr<VoxelScene>> scenes;
+    int stripRows; std::vector<vrt_comm*> comms; std::vector<std::unique_ptr<GeometryStage>> stages; std::unique_ptr<DenoiserStage> denoiser;
+    GeometryBuffer full; std::vector<std::shared_ptr<DeviceBuffer<uint8_t>>> packed; std::shared_ptr<DeviceBuffer<uint8_t>> gathered;
+};
+
 } // namespace vrt_host
