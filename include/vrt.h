@@ -278,6 +278,12 @@ int  vrt_pack_halo(vrt_ctx* ctx, const void* full, void* packed, int32_t W, int3
 int  vrt_unpack_halo(vrt_ctx* ctx, const void* packed, void* full, int32_t W, int32_t H,
                      int32_t bytes_per_px, const vrt_shard* shard, int32_t halo, int32_t dir);
 size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bytes_per_px, const vrt_shard* shard, int32_t halo);
+/* The halo rows of n images in one launch per 64 (the frames of a batch; shards[n]: each image's own strip assignment --
+ * for unpack the SENDER's): one ring exchange per step then carries the colour, normal and position rows of every frame. */
+int  vrt_pack_halo_batch(vrt_ctx* ctx, int32_t n, const void* const* full, void* const* packed, int32_t W, int32_t H,
+                         int32_t bytes_per_px, const vrt_shard* shards, int32_t halo, int32_t dir);
+int  vrt_unpack_halo_batch(vrt_ctx* ctx, int32_t n, const void* const* packed, void* const* full, int32_t W, int32_t H,
+                           int32_t bytes_per_px, const vrt_shard* shards, int32_t halo, int32_t dir);
 
 /* ---- the collective itself, for hosts without torch.distributed (no reference analogue; BASELINE north_star: "C++ host code
  * ... RCCL gather over xGMI") ---------------------------------------------------------------------------------------------

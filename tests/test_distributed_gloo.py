@@ -186,3 +186,135 @@ def test_sharded_batch_step_protocol_gloo(world, mode):
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) == 1
+
+
+def _denoise_worker(rank, world, port, q, mode):
+    """ShardedBatch.step with denoise=True on CPU: the real step / denoise_step / exchange_halo / collective code over gloo,
+    the device work (tracing, halo packing, the filter) replaced by numpy row maps and the oracle's denoiser."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import voxel_raytracing_amd as vrt
+    from oracle import oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = vrt.distributed
+    owners = mode == "owners"
+    W, H, SR, FB = 24, 70, 16, 2
+    F = world * FB if owners else 3
+    iters, sw0 = 2, 1.0                                        # reach 1 + 2: halo 3, extents 2 and 0
+    halo = 3
+    rng = np.random.default_rng(7)
+    color = rng.integers(0, 256, (F, H, W, 4), dtype=np.uint8)
+    normal = np.zeros((F, H, W, 4), np.int8); normal[..., 0] = 127; normal[:, :, W // 2:, 0] = 0; normal[:, :, W // 2:, 1] = 127
+    pos = np.zeros((F, H, W, 4), np.float32)
+    pos[..., 0] = np.arange(W)[None, None, :] * 0.25; pos[..., 1] = np.arange(H)[None, :, None] * 0.25; pos[:, H // 3:, :, 2] = 2.0
+    want = np.stack([oracle.denoise(color[f], normal[f], pos[f], iterations=iters, step_width0=sw0) for f in range(F)])
+    prow = D.packed_rows(H, world, SR)
+    mls = D.max_local_strips(H, world, SR)
+
+    sb = D.ShardedBatch.__new__(D.ShardedBatch)
+    sb.rank, sb.nranks, sb.group, sb.F, sb.W, sb.H, sb.strip_rows = rank, world, None, F, W, H, SR
+    sb.owners, sb.rotate, sb.FB, sb.host_staged, sb.denoise, sb.direct = owners, owners, FB, False, True, False
+    sb.packed = torch.zeros((F, prow, W, 4), dtype=torch.uint8)
+    sb._root = None
+    mine_frames = list(sb.owned_frames())
+    if mine_frames:
+        sb.finals = torch.zeros((len(mine_frames), H, W, 4), dtype=torch.uint8)
+    vr = lambda f, r=None: (sb.virtual_rank(rank if r is None else r, f // FB) if owners else (rank if r is None else r))
+    planes = {}
+
+    def render(pushes):                                        # a rank holds its own rows of every plane, zeros elsewhere
+        for name, full in (("c", color), ("n", normal), ("p", pos)):
+            planes[name] = np.zeros_like(full)
+            for f in range(F):
+                own = D.owned_rows(H, vr(f), world, SR)
+                planes[name][f][own] = full[f][own]
+    sb.render = render
+
+    def pack_halos():
+        ups, downs = [], []
+        for name in ("c", "n", "p"):
+            for f in range(F):
+                a = planes[name][f].reshape(H, -1).view(np.uint8)
+                ups.append(D.pack_np(a, D.halo_row_map(H, vr(f), world, SR, halo, -1)).reshape(-1))
+                downs.append(D.pack_np(a, D.halo_row_map(H, vr(f), world, SR, halo, +1)).reshape(-1))
+        return torch.from_numpy(np.concatenate(ups)), torch.from_numpy(np.concatenate(downs))
+    sb.pack_halos = pack_halos
+
+    def unpack_halos(from_below, from_above):
+        o = 0
+        for name, bpp in (("c", 4), ("n", 4), ("p", 16)):
+            for f in range(F):
+                n = mls * halo * W * bpp
+                for buf, src, d in ((from_below, (rank + 1) % world, -1), (from_above, (rank - 1) % world, +1)):
+                    a = planes[name][f].reshape(H, -1).view(np.uint8)
+                    D.unpack_np(buf.numpy()[o:o + n].reshape(mls * halo, W * bpp), a, D.halo_row_map(H, vr(f, src), world, SR, halo, d))
+                o += n
+    sb.unpack_halos = unpack_halos
+
+    den = {}
+    def run_denoiser():                                        # the filter over what this rank holds: right on its own rows
+        for f in range(F):
+            den[f] = oracle.denoise(planes["c"][f], planes["n"][f], planes["p"][f], iterations=iters, step_width0=sw0)
+    sb.run_denoiser = run_denoiser
+
+    def pack():
+        for f in range(F):
+            sb.packed[f] = torch.from_numpy(D.pack_np(den[f], D.packed_row_map(H, vr(f), world, SR)))
+        return sb.packed
+    sb.pack = pack
+
+    def recv_buffers():
+        if sb._root is None:
+            sb._root = (torch.empty_like(sb.packed) if owners else [torch.empty_like(sb.packed) for _ in range(world)],)
+        return sb._root[0]
+    sb.recv_buffers = recv_buffers
+
+    def assemble():
+        out = np.zeros((len(mine_frames), H, W, 4), np.uint8)
+        if owners:
+            for src in range(world):
+                for j in range(FB):
+                    D.unpack_np(sb._root[0][src * FB + j].numpy(), out[j], D.packed_row_map(H, sb.virtual_rank(src, rank), world, SR))
+        else:
+            for src, b in enumerate(sb._root[0]):
+                for f in range(F):
+                    D.unpack_np(b[f].numpy(), out[f], D.packed_row_map(H, src, world, SR))
+        sb.finals.copy_(torch.from_numpy(out))
+        return sb.finals
+    sb.assemble = assemble
+
+    out = sb.step(None, overlap=False)
+    ok = True
+    if mine_frames:
+        ok = bool((out.numpy() == want[mine_frames]).all())
+    else:
+        ok = out is None
+    sb.step(None, overlap=True)                                  # and the overlapped form: completed by finish()
+    last = sb.finish()
+    if mine_frames:
+        ok = ok and bool((last.numpy() == want[mine_frames]).all())
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        q.put(int(t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["root", "owners"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_batch_denoise_halo_exchange_gloo(world, mode):
+    """The batched, sharded denoiser path (one packed ring exchange of halo rows per step) equals the unsharded filter."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_denoise_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == 1

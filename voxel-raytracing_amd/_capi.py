@@ -112,6 +112,8 @@ SYMBOLS = {
     "vrt_unpack_rows": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
     "vrt_pack_rows_batch": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
     "vrt_unpack_rows_batch": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
+    "vrt_pack_halo_batch": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
+    "vrt_unpack_halo_batch": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
     "vrt_pack_halo": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
     "vrt_unpack_halo": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32, C.c_int32]),
     "vrt_halo_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard), C.c_int32]),

@@ -950,7 +950,7 @@ int vrt_unpack_halo(vrt_ctx* c, const void* packed, void* full, int32_t W, int32
 
 // n images per launch (chunks of VRT_ROWS_BATCH).  shards: one map for all images (per_image == 0) or one per image.
 static int rows_batch_call(vrt_ctx* c, int n, const void* const* src, void* const* dst, int W, int H, int bpp,
-                           const vrt_shard* shards, int per_image, int unpack)
+                           const vrt_shard* shards, int per_image, int unpack, int halo = 0, int dir = 0)
 {
     if (!c || !src || !dst) return fail(VRT_ERR_INVALID, "strip copy (batch): NULL argument");
     if (n < 0 || W <= 0 || H <= 0 || bpp <= 0) return fail(VRT_ERR_INVALID, "strip copy (batch): bad size");
@@ -959,7 +959,7 @@ static int rows_batch_call(vrt_ctx* c, int n, const void* const* src, void* cons
         const int m = n - i0 < VRT_ROWS_BATCH ? n - i0 : VRT_ROWS_BATCH;
         RowsBatchParams p;
         memset(&p, 0, sizeof p);
-        p.W = W; p.H = H; p.bpp = bpp; p.unpack = unpack;
+        p.W = W; p.H = H; p.bpp = bpp; p.unpack = unpack; p.halo = halo; p.dir = dir;
         int rows = 0;
         for (int k = 0; k < m; k++) {
             if (!src[i0 + k] || !dst[i0 + k]) return fail(VRT_ERR_INVALID, "strip copy (batch): NULL image pointer");
@@ -967,7 +967,8 @@ static int rows_batch_call(vrt_ctx* c, int n, const void* const* src, void* cons
             int rc = make_shard(per_image ? &shards[i0 + k] : shards, H, p.sh[k], &mx);
             if (rc != VRT_OK) return rc;
             p.src[k] = (const uint8_t*)src[i0 + k]; p.dst[k] = (uint8_t*)dst[i0 + k];
-            int r = p.sh[k].nranks == 1 ? H : mx * p.sh[k].strip_rows;
+            if (halo > p.sh[k].strip_rows) return fail(VRT_ERR_INVALID, "strip copy (batch): halo larger than strip_rows");
+            int r = halo ? mx * halo : (p.sh[k].nranks == 1 ? H : mx * p.sh[k].strip_rows);
             rows = r > rows ? r : rows;
         }
         HIPCHK(launch_rows_batch(p, rows, m, c->stream));
@@ -984,6 +985,22 @@ int vrt_unpack_rows_batch(vrt_ctx* c, int32_t n, const void* const* packed, void
 {
     if (!shards) return fail(VRT_ERR_INVALID, "vrt_unpack_rows_batch: one vrt_shard per image is required");
     return rows_batch_call(c, n, packed, full, W, H, bpp, shards, 1, 1);
+}
+
+int vrt_pack_halo_batch(vrt_ctx* c, int32_t n, const void* const* full, void* const* packed, int32_t W, int32_t H, int32_t bpp,
+                        const vrt_shard* shards, int32_t halo, int32_t dir)
+{
+    if (!shards) return fail(VRT_ERR_INVALID, "vrt_pack_halo_batch: one vrt_shard per image is required");
+    if (halo <= 0 || (dir != -1 && dir != 1)) return fail(VRT_ERR_INVALID, "vrt_pack_halo_batch: halo > 0 and dir = +-1 required");
+    return rows_batch_call(c, n, full, packed, W, H, bpp, shards, 1, 0, halo, dir);
+}
+
+int vrt_unpack_halo_batch(vrt_ctx* c, int32_t n, const void* const* packed, void* const* full, int32_t W, int32_t H, int32_t bpp,
+                          const vrt_shard* shards, int32_t halo, int32_t dir)
+{
+    if (!shards) return fail(VRT_ERR_INVALID, "vrt_unpack_halo_batch: one vrt_shard per image is required");
+    if (halo <= 0 || (dir != -1 && dir != 1)) return fail(VRT_ERR_INVALID, "vrt_unpack_halo_batch: halo > 0 and dir = +-1 required");
+    return rows_batch_call(c, n, packed, full, W, H, bpp, shards, 1, 1, halo, dir);
 }
 
 size_t vrt_halo_bytes(int32_t W, int32_t H, int32_t bpp, const vrt_shard* sh, int32_t halo)

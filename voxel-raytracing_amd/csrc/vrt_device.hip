@@ -1350,7 +1350,16 @@ __global__ __launch_bounds__(256) void k_rows_batch(const RowsBatchParams P)
 {
     const int r = blockIdx.x, img = blockIdx.y;
     const ShardMap sh = P.sh[img];
-    const int y = strip_row(sh, 0, r, P.H);
+    int y;
+    if (P.halo == 0) y = strip_row(sh, 0, r, P.H);
+    else {                                                     // halo rows of strip k = r / halo (as k_rows)
+        const int k = r / P.halo, j = r % P.halo;
+        const int g = k * sh.nranks + sh.rank;
+        const int beg = g * sh.strip_rows;
+        int end = beg + sh.strip_rows; if (end > P.H) end = P.H;
+        y = (P.dir < 0) ? beg + j : end - P.halo + j;
+        if (y < beg || y >= end) y = -1;
+    }
     const size_t row_bytes = (size_t)P.W * (size_t)P.bpp;
     const uint8_t* src; uint8_t* dst;
     if (y < 0) {

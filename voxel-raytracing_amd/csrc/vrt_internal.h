@@ -203,6 +203,7 @@ struct RowsBatchParams {     // strip pack / unpack of many images in one launch
     uint8_t*       dst[VRT_ROWS_BATCH];
     ShardMap       sh[VRT_ROWS_BATCH];
     int32_t W, H, bpp, unpack;
+    int32_t halo, dir;       // halo > 0: the first (dir < 0) / last (dir > 0) `halo` rows of every owned strip instead of whole strips
 };
 
 struct BlitParams {

@@ -218,7 +218,12 @@ class ShardedFrame:
 class ShardedBatch:
     """Per-rank driver for a batch of F frames (consecutive camera poses): ONE K1 launch over this rank's strips of all of
     them (vrt_render_geometry_batch / _slots), strip packing, ONE collective per step, strip unpacking at the receivers.
-    Geometry only (the denoiser needs the halo exchange of ShardedFrame).
+    denoise=True runs the sharded denoiser on every frame of the batch between the tracing and the collective: ONE ring
+    exchange per step carries the halo rows (first / last `halo` rows of every owned strip) of the colour, normal and position
+    planes of ALL frames to the two ring neighbours -- two packed buffers out, two in (exchange_halo) -- then each frame is
+    filtered on its owner's rows (vrt_denoise with the frame's strip assignment) and the filtered colour is what is packed.
+    With the rotating assignment block b is traced as virtual rank (rank + b) % N by every rank, so a strip's neighbours are
+    the same two real ranks for every block.
 
     assemble_on = "root":   every frame is gathered to rank 0 (dist.gather): the single-display case.  Rank 0 receives
                             (N-1)/N of every frame of the batch over its 7 inbound xGMI links, so the batch rate is bound by
@@ -239,8 +244,11 @@ class ShardedBatch:
                             collective."""
 
     def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False,
-                 assemble_on: str = "root", rotate: bool = None, direct: bool = True, side_unpack: bool = False):
+                 assemble_on: str = "root", rotate: bool = None, direct: bool = True, side_unpack: bool = False, denoise: bool = False):
         import torch
+        self.denoise = bool(denoise) and bool(stage._settings.denoiserSettings.enable) and int(nranks) > 1
+        if self.denoise:
+            direct = False                                     # the colour that travels is the denoiser's output, not K1's
         self.stage, self.F = stage, int(n_frames)
         self.host_staged = bool(host_staged)       # collective through host memory (gloo rehearsal of the N > 1 path on one GPU)
         self.side_unpack = bool(side_unpack) and not self.host_staged      # assemble received frames on a second stream
@@ -292,6 +300,86 @@ class ShardedBatch:
                 self.finals = torch.zeros((self.FB, H, W, 4), dtype=torch.uint8, device=dev)
             elif rank == 0:
                 self.finals = torch.zeros((self.F, H, W, 4), dtype=torch.uint8, device=dev)
+
+    # -- sharded denoiser inside the batch ------------------------------------------------------------------------------
+    def frame_shard(self, f: int, rank: int = None) -> "_capi.Shard":
+        """The strip assignment frame f of the batch is traced with by `rank` (default: this rank)."""
+        rank = self.rank if rank is None else rank
+        vr = self.virtual_rank(rank, f // self.FB) if self.owners else rank
+        return _capi.Shard(vr, self.nranks, self.strip_rows)
+
+    def _halo_setup(self):
+        import torch
+        lib = _capi.lib()
+        ds = self.stage._settings.denoiser_to_c()
+        self._ds = ds
+        self.halo = int(lib.vrt_denoise_halo_rows(C.byref(ds)))
+        if self.halo > self.strip_rows:
+            raise ValueError(f"denoiser halo ({self.halo} rows) exceeds strip_rows ({self.strip_rows}); use larger strips")
+        mls = max_local_strips(self.H, self.nranks, self.strip_rows)
+        dev = self.stage.engine.torch_device
+        P = C.c_void_p
+        self._planes = (("color8", 4), ("normal8", 4), ("position", 16))
+        rows = mls * self.halo
+        # [plane][frame][rows][W][bpp] in ONE buffer per direction: colour, normal, position of every frame
+        sizes = [self.F * rows * self.W * bpp for _, bpp in self._planes]
+        self._halo_off = [0, sizes[0], sizes[0] + sizes[1]]
+        total = sum(sizes)
+        self._send_up, self._send_down = torch.zeros(total, dtype=torch.uint8, device=dev), torch.zeros(total, dtype=torch.uint8, device=dev)
+        up, down = (self.rank - 1) % self.nranks, (self.rank + 1) % self.nranks
+        self._halo_tabs = []
+        for k, (name, bpp) in enumerate(self._planes):
+            full = (P * self.F)(*[g.planes[name].data_ptr() for g in self.gbs])
+            def sub(buf, k=k, bpp=bpp):
+                return (P * self.F)(*[buf.data_ptr() + self._halo_off[k] + f * rows * self.W * bpp for f in range(self.F)])
+            mine = (_capi.Shard * self.F)(*[self.frame_shard(f) for f in range(self.F)])
+            below = (_capi.Shard * self.F)(*[self.frame_shard(f, down) for f in range(self.F)])     # sender of from_below
+            above = (_capi.Shard * self.F)(*[self.frame_shard(f, up) for f in range(self.F)])
+            self._halo_tabs.append((bpp, full, sub, mine, below, above))
+        self._den_targets = [[torch.zeros_like(g.color), torch.zeros_like(g.color)] for g in self.gbs]
+        self._den_out = [None] * self.F
+
+    def pack_halos(self):
+        """First / last `halo` rows of every owned strip of every frame, three planes, into the two send buffers."""
+        if getattr(self, "_halo_tabs", None) is None:
+            self._halo_setup()
+        lib, ctx = _capi.lib(), self.stage.engine.ctx
+        for bpp, full, sub, mine, _, _ in self._halo_tabs:
+            _capi.check(lib.vrt_pack_halo_batch(ctx, self.F, full, sub(self._send_up), self.W, self.H, bpp, mine, self.halo, -1))
+            _capi.check(lib.vrt_pack_halo_batch(ctx, self.F, full, sub(self._send_down), self.W, self.H, bpp, mine, self.halo, 1))
+        return self._send_up, self._send_down
+
+    def unpack_halos(self, from_below, from_above):
+        """The neighbours' rows into the guide planes, just outside this rank's strips."""
+        lib, ctx = _capi.lib(), self.stage.engine.ctx
+        P = C.c_void_p
+        rows = max_local_strips(self.H, self.nranks, self.strip_rows) * self.halo
+        for k, (bpp, full, _, _, below, above) in enumerate(self._halo_tabs):
+            def sub(buf, k=k, bpp=bpp):
+                return (P * self.F)(*[buf.data_ptr() + self._halo_off[k] + f * rows * self.W * bpp for f in range(self.F)])
+            _capi.check(lib.vrt_unpack_halo_batch(ctx, self.F, sub(from_below), full, self.W, self.H, bpp, below, self.halo, -1))
+            _capi.check(lib.vrt_unpack_halo_batch(ctx, self.F, sub(from_above), full, self.W, self.H, bpp, above, self.halo, 1))
+
+    def run_denoiser(self):
+        """vrt_denoise on every frame's own rows; afterwards pack() takes the filtered colour."""
+        lib, ctx = _capi.lib(), self.stage.engine.ctx
+        for f, g in enumerate(self.gbs):
+            res = C.c_void_p()
+            sh = self.frame_shard(f)
+            t0, t1 = self._den_targets[f]
+            _capi.check(lib.vrt_denoise(ctx, self.W, self.H, C.byref(self._ds), g.color.data_ptr(), g.normal.data_ptr(), g.position.data_ptr(),
+                                        t0.data_ptr(), t1.data_ptr(), C.byref(sh), C.byref(res)))
+            self._den_out[f] = t0 if res.value == t0.data_ptr() else (t1 if res.value == t1.data_ptr() else g.color)
+        P = C.c_void_p
+        self._full_ptrs = (P * self.F)(*[t.data_ptr() for t in self._den_out])
+        self._pack_tabs = None
+
+    def denoise_step(self):
+        """Between render() and pack(): one packed ring exchange of the halo rows, then the sharded filter."""
+        up, down = self.pack_halos()
+        from_below, from_above = exchange_halo(up, down, self.group)
+        self.unpack_halos(from_below, from_above)
+        self.run_denoiser()
 
     def virtual_rank(self, rank: int, block: int) -> int:
         """The strip assignment `rank` traces frame block `block` with."""
@@ -455,6 +543,8 @@ class ShardedBatch:
         gbs = self.render(pushes)
         if self.nranks <= 1:
             return gbs
+        if getattr(self, "denoise", False):
+            self.denoise_step()
         if not overlap:
             self.pack()
             return self.gather()
