@@ -43,7 +43,7 @@ void* th_create(const uint8_t* vox, int W, int H, int D)
     build_up(h->o2, v.n2x, v.n2y, v.n2z, h->o3, v.n3x, v.n3y, v.n3z);
     // clearance fields: per octant three one-sided 1-D min-max passes (same definition as k_df_pass, written independently)
     {
-        const int CAP = 63;
+        const int CAP = 127;
         size_t stride = df_field_bytes(W, H, D);                 // padded x-fastest fields (vrt_traverse.h df_index)
         h->df.assign(8 * stride, 0);
         std::vector<uint8_t> a((size_t)W * H * D), b((size_t)W * H * D);

@@ -92,7 +92,7 @@ hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_
 // than one voxel past a wall.
 // ---------------------------------------------------------------------------------------------
 
-#define VRT_DF_CAP 63
+#define VRT_DF_CAP 127      // >= 64: a 64-iteration AO ray that starts in the open is decided by its first look-up (trace_df_fast, any-hit)
 
 // src == nullptr: first pass, the field is (vox != 0 ? 0 : INF).
 __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox, const uint8_t* __restrict__ src,
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void k_df_pass(const uint8_t* __restrict__ vox
 // df: 8 * stride bytes (stride = df_field_bytes: one zero-bordered field); tmp0/tmp1: W*H*D bytes each
 hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int cap)
 {
+    if (cap <= 0) cap = VRT_DF_CAP;
     size_t n = (size_t)W * H * D;
     unsigned blocks = (unsigned)((n + 255) / 256);
     for (int o = 0; o < 8; o++) {
@@ -458,7 +459,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
             f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
             RayInt r;
             // AO rays have a 64-iteration budget: too short for jumps to pay, and budget ties would force re-traces
-            trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV)>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);
+            trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV), decltype(occ.o2), false, true>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);
             c.fetches += r.fetches; c.rays++;
             if (r.material != 0) ambient += sample_frac;
         }
@@ -482,7 +483,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
     if (SEC && st.shadows) {
         f3 o = mk3(hit.pos.x + hit.normal.x * 0.01f, hit.pos.y + hit.normal.y * 0.01f, hit.pos.z + hit.normal.z * 0.01f);
         RayInt r;
-        trace_int<TRAV>(s.vol, occ.o2, occ.o3, o, L, st.max_steps, r);
+        trace_int<TRAV, decltype(occ.o2), false, true>(s.vol, occ.o2, occ.o3, o, L, st.max_steps, r);      // traceRayHit: only "did it hit" is used
         c.fetches += r.fetches; c.rays++;
         shadowed = r.material != 0;
     }

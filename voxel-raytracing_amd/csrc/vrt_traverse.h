@@ -802,7 +802,7 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
                                              float& x, float& y, float& z, float dx, float dy, float dz,
                                              float gx, float gy, float gz, float cx, float cy, float cz,
                                              uint32_t idx0, uint32_t voxoff, uint32_t& lmask, uint32_t& material, uint32_t& fetches,
-                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz)
+                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz, uint32_t anyhit)
 {
     // the same iteration that also moves the index of the lane's voxel: one more vector instruction per axis under the
     // EXEC mask that is there anyway -- cheaper than recovering the position afterwards for runs of up to four iterations
@@ -847,6 +847,36 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "10:\n\t"                                                   // ---- look-up: every lane's byte is here ----
         "s_waitcnt vmcnt(0)\n\t"
         "11:\n\t"
+        // any-hit rays (AO, shadow): a lane whose clearance covers what is left of its budget will test nothing but empty voxels
+        // until the budget ends -- it is a miss with fetches = maxSteps, decided here without stepping (a 64-iteration AO ray
+        // that starts in the open: by its first look-up; the fields hold clearances up to 127)
+        "s_cmp_eq_u32 %[any], 0\n\t"
+        "s_cbranch_scc1 111f\n\t"
+        "s_sub_u32 s62, %[maxs], s60\n\t"
+        "v_cmp_le_u32_e32 vcc, s62, v52\n\t"                        // left <= clearance ...
+        "v_cmp_ne_u32_e64 s[64:65], s63, v52\n\t"                   // ... of a lane that is still live
+        "s_and_b64 vcc, vcc, s[64:65]\n\t"
+        "s_cbranch_vccz 111f\n\t"
+        "s_and_saveexec_b64 s[66:67], vcc\n\t"
+        "v_mov_b32 %[fet], %[maxs]\n\t"
+        "v_mov_b32 %[dx], 0\n\t"
+        "v_mov_b32 %[dy], 0\n\t"
+        "v_mov_b32 %[dz], 0\n\t"
+        "v_mov_b32 %[gx], 0\n\t"
+        "v_mov_b32 %[gy], 0\n\t"
+        "v_mov_b32 %[gz], 0\n\t"
+        "v_mov_b32 %[cx], 0\n\t"
+        "v_mov_b32 %[cy], 0\n\t"
+        "v_mov_b32 %[cz], 0\n\t"
+        "v_mov_b32 %[ix], 0\n\t"
+        "v_mov_b32 %[iy], 0\n\t"
+        "v_mov_b32 %[iz], 0\n\t"
+        "v_mov_b32 %[idx0], %[sent]\n\t"
+        "v_mov_b32 v53, %[sent]\n\t"
+        "v_mov_b32 v52, s63\n\t"
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "s_nop 4\n\t"
+        "111:\n\t"
         "v_cmp_gt_u32_e32 vcc, 2, v52\n\t"                          // 0 (solid / border) or 1 (single iteration) somewhere?
         "s_cbranch_vccnz 15f\n\t"
         "v_cmp_gt_u32_e32 vcc, 4, v52\n\t"                          // 2 or 3 somewhere (and nothing below)?
@@ -1053,14 +1083,14 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
           [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
           [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), [fet] "+v"(fetches),
           [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz)
-        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
+        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [any] "s"(anyhit)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53",
-          "s60", "s61", "s62", "s63", "s66", "s67", "s68", "s69");
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69");
 #undef VRT_F_EITER
 #undef VRT_F_EITER_IDX
 }
 
-template <class STATS>
+template <class STATS, bool ANYHIT = false>
 __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -1095,14 +1125,14 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));      // (the builtin returns int)
     df_fast_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
-                 incx, incy, incz);
+                 incx, incy, incz, ANYHIT ? 1u : 0u);
     s.sdx = x; s.sdy = y; s.sdz = z;
     finish(s, material, lmask, fetches + (material != 0u ? 1u : 0u), r);
     (void)stats;
 }
 #else
 // host pass of a .hip file / the host build of the unit tests: parsed, never run (the loop is gfx950 assembly)
-template <class STATS>
+template <class STATS, bool ANYHIT = false>
 VRT_HD void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 #endif
 
@@ -1562,7 +1592,9 @@ VRT_HD void trace_dfj(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, 
 }
 
 // Dispatcher used by the kernels.
-template <int TRAV, class OP, bool AHEAD = false>
+// ANYHIT: the caller only uses r.material and r.fetches (traceRayHit, frag:198-202): a traversal may then stop stepping a ray
+// that is certain to exhaust its budget in empty space (DF_FAST does)
+template <int TRAV, class OP, bool AHEAD = false, bool ANYHIT = false>
 VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
                       uint32_t maxSteps, RayInt& r)
 {
@@ -1574,7 +1606,7 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
         trace_brick(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
-        trace_df_fast(v, start, dir, maxSteps, r, ns);
+        trace_df_fast<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF) {
         NoStats ns;
         trace_df<NoStats, AHEAD>(v, start, dir, maxSteps, r, ns);
