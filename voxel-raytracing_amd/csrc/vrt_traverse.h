@@ -1161,7 +1161,7 @@ VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_
     if (c != 0u) {                                             // an empty brick with c - 1 empty bricks behind it on every axis
         const uint32_t rx = sx > 0 ? 8u - lx : lx + 1u, ry = sy > 0 ? 8u - ly : ly + 1u, rz = sz > 0 ? 8u - lz : lz + 1u;
         const uint32_t k = (c - 1u) * 8u + umin3(rx, ry, rz);
-        return k < 63u ? k : 63u;
+        return k < 127u ? k : 127u;
     }
     const uint32_t ptr = v.bgrid[bi];
     if (ptr + 1u <= 1u) return 0u;                             // the border (0xFFFFFFFF): the ray has left the volume
@@ -1171,7 +1171,7 @@ VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_
     return f;
 }
 
-template <class STATS>
+template <class STATS, bool ANYHIT = false>
 VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -1215,6 +1215,9 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
 #if defined(__HIP_DEVICE_COMPILE__)
                     lmask = lane_bits(kx, ky, kz);
 #endif
+                } else if (ANYHIT && clear >= maxSteps - i) {
+                    // any-hit ray whose clearance covers the rest of its budget: a miss with fetches = maxSteps, no stepping
+                    done = true; fetches = maxSteps;
                 }
             }
         }
@@ -1603,7 +1606,7 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
         trace_jump(v, o2, o3, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_BRICK) {
         NoStats ns;
-        trace_brick(v, start, dir, maxSteps, r, ns);
+        trace_brick<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
         trace_df_fast<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
