@@ -80,6 +80,109 @@ void* th_create(const uint8_t* vox, int W, int H, int D)
 
 void th_destroy(void* p) { delete (HostVolume*)p; }
 
+} // extern "C"
+
+// ---- brick scenes: the two-level clearance of vrt_scene_from_bricks, built here by plain definitions -----------------------
+// (an independent builder: the traversal only needs SOME lower bound of the true clearance, so the fields need not equal the
+// device builder's -- the coarse field is the largest cube of empty bricks, the fine field the true clearance capped at 16)
+struct HostBricks {
+    VolumeView v;
+    std::vector<uint32_t> grid;
+    std::vector<uint8_t> coarse, pool, fine;
+};
+
+// clearance of every cell of a W x H x D occupancy (outside = solid) towards octant o, capped: three one-sided min-max passes
+static std::vector<uint8_t> octant_clearance(const std::vector<uint8_t>& solid, int W, int H, int D, int o, int cap)
+{
+    std::vector<uint8_t> a((size_t)W * H * D), b((size_t)W * H * D);
+    const int sg[3] = {(o & 1) ? 1 : -1, (o & 2) ? 1 : -1, (o & 4) ? 1 : -1};
+    for (size_t i = 0; i < a.size(); i++) a[i] = solid[i] ? 0 : (uint8_t)(cap + 1);
+    for (int axis = 0; axis < 3; axis++) {
+        for (int z = 0; z < D; z++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+            const size_t i = (size_t)x + ((size_t)y + (size_t)z * H) * W;
+            const int pos = axis == 0 ? x : (axis == 1 ? y : z), dim = axis == 0 ? W : (axis == 1 ? H : D);
+            const long long st = (axis == 0 ? 1 : (axis == 1 ? (long long)W : (long long)W * H)) * sg[axis];
+            int best = a[i];
+            for (int t = 1; t < best; t++) {
+                const int q = pos + t * sg[axis];
+                const int val = (q < 0 || q >= dim) ? 0 : a[(long long)i + t * st];
+                const int m = val > t ? val : t;
+                if (m < best) best = m;
+            }
+            b[i] = (uint8_t)best;
+        }
+        a.swap(b);
+    }
+    for (auto& c : a) if (c > cap) c = (uint8_t)cap;
+    return a;
+}
+
+extern "C" {
+
+void* thb_create(const uint8_t* vox, int W, int H, int D)                // dimensions: multiples of 8
+{
+    HostBricks* h = new HostBricks();
+    VolumeView& v = h->v;
+    memset(&v, 0, sizeof v);
+    v.W = W; v.H = H; v.D = D;
+    const int nbx = W / 8, nby = H / 8, nbz = D / 8, pbx = nbx + 2, pby = nby + 2, pbz = nbz + 2;
+    v.pbx = pbx; v.pby = pby;
+    h->grid.assign((size_t)pbx * pby * pbz, 0xFFFFFFFFu);
+    std::vector<uint8_t> occ((size_t)nbx * nby * nbz, 0), solid((size_t)W * H * D);
+    for (size_t i = 0; i < solid.size(); i++) solid[i] = vox[i] != 0;
+    std::vector<std::vector<uint8_t>> dense(8);
+    for (int o = 0; o < 8; o++) dense[o] = octant_clearance(solid, W, H, D, o, 16);
+    uint32_t n = 0;
+    for (int bz = 0; bz < nbz; bz++) for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
+        bool any = false;
+        for (int z = 0; z < 8 && !any; z++) for (int y = 0; y < 8 && !any; y++) for (int x = 0; x < 8; x++)
+            if (vox[(size_t)(bx * 8 + x) + ((size_t)(by * 8 + y) + (size_t)(bz * 8 + z) * H) * W]) { any = true; break; }
+        const size_t pi = (size_t)(bx + 1) + ((size_t)(by + 1) + (size_t)(bz + 1) * pby) * pbx;
+        h->grid[pi] = any ? ++n : 0u;
+        occ[(size_t)bx + ((size_t)by + (size_t)bz * nby) * nbx] = any;
+        if (!any) continue;
+        for (int z = 0; z < 8; z++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++)
+            h->pool.push_back(vox[(size_t)(bx * 8 + x) + ((size_t)(by * 8 + y) + (size_t)(bz * 8 + z) * H) * W]);
+        for (int o = 0; o < 8; o++)
+            for (int z = 0; z < 8; z++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++)
+                h->fine.push_back(dense[o][(size_t)(bx * 8 + x) + ((size_t)(by * 8 + y) + (size_t)(bz * 8 + z) * H) * W]);
+    }
+    const size_t cstride = (size_t)pbx * pby * pbz;
+    h->coarse.assign(8 * cstride, 0);
+    for (int o = 0; o < 8; o++) {
+        std::vector<uint8_t> c = octant_clearance(occ, nbx, nby, nbz, o, 16);
+        for (int bz = 0; bz < nbz; bz++) for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++)
+            h->coarse[(size_t)o * cstride + (size_t)(bx + 1) + ((size_t)(by + 1) + (size_t)(bz + 1) * pby) * pbx] = c[(size_t)bx + ((size_t)by + (size_t)bz * nby) * nbx];
+    }
+    if (h->pool.empty()) { h->pool.push_back(0); h->fine.push_back(0); }
+    v.bgrid = h->grid.data(); v.bcoarse = h->coarse.data(); v.bcoarse_stride = cstride; v.bpool = h->pool.data(); v.bfine = h->fine.data();
+    return h;
+}
+
+void thb_destroy(void* p) { delete (HostBricks*)p; }
+
+// same output record as th_trace; anyhit != 0: the any-hit form (only material and fetches are defined)
+void thb_trace(void* p, int n, const float* starts, const float* dirs, uint32_t maxSteps, int anyhit, uint32_t* out, uint64_t* lookups)
+{
+    HostBricks* h = (HostBricks*)p;
+    TraceStats total;
+    for (int i = 0; i < n; i++) {
+        f3 s = mk3(starts[i * 3], starts[i * 3 + 1], starts[i * 3 + 2]);
+        f3 d = mk3(dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]);
+        RayInt r;
+        TraceStats st;
+        if (anyhit) trace_brick<TraceStats, true>(h->v, s, d, maxSteps, r, st);
+        else        trace_brick<TraceStats, false>(h->v, s, d, maxSteps, r, st);
+        total.lookups += st.lookups;
+        uint32_t* o = out + (size_t)i * 12;
+        o[0] = r.material; o[1] = r.material ? r.mask : 0; o[2] = r.material ? (uint32_t)r.mx : 0; o[3] = r.material ? (uint32_t)r.my : 0;
+        o[4] = r.material ? (uint32_t)r.mz : 0;
+        o[5] = r.material ? f2u(r.side.x) : 0; o[6] = r.material ? f2u(r.side.y) : 0; o[7] = r.material ? f2u(r.side.z) : 0;
+        o[8] = f2u(r.pos.x); o[9] = f2u(r.pos.y); o[10] = f2u(r.pos.z); o[11] = r.fetches;
+    }
+    if (lookups) *lookups = total.lookups;
+}
+
 // out per ray: 12 uint32: material, mask, mx,my,mz, side bits x3, p bits x3, fetches ; stats: 6 uint32 summed
 void th_trace(void* p, int trav, int n, const float* starts, const float* dirs, uint32_t maxSteps, uint32_t* out, uint64_t* stats)
 {

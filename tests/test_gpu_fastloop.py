@@ -135,8 +135,9 @@ def test_fast_loop_secondary_rays(vrt, oracle, engine, split):
 
 
 def test_fast_loop_random_sweep(vrt, oracle, engine):
-    rng = np.random.default_rng(2024)
-    for case in range(80):
+    # VRT_SWEEP_CASES / VRT_SWEEP_SEED: longer runs of the same sweep (DESIGN.md quotes one of 20 000 cases)
+    rng = np.random.default_rng(int(os.environ.get("VRT_SWEEP_SEED", "2024")))
+    for case in range(int(os.environ.get("VRT_SWEEP_CASES", "80"))):
         kind = int(rng.integers(0, 4))
         if kind == 0:   vol = vrt.synthetic.floating_cubes(int(rng.integers(16, 72)), seed=int(rng.integers(1, 1 << 30)), count=int(rng.integers(1, 200)))
         elif kind == 1: vol = vrt.synthetic.sparse_bricks(int(rng.choice([32, 48, 64])), int(rng.choice([2, 4, 8])), float(rng.uniform(0.005, 0.3)), seed=int(rng.integers(1, 1 << 30)))
