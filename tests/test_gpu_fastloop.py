@@ -13,11 +13,14 @@ pytestmark = pytest.mark.gpu
 
 GB = ["color8", "depth", "motion", "mask8", "position", "normal8"]
 PLANES = GB + ["color_f", "hit_id", "hit_mask", "steps_primary", "steps_total", "rays_total"]     # everything but hit_voxel
+# without the count planes a launch marches through the fields WITH open cells (rays end where nothing solid is left in their
+# octant): what a caller of the product gets; with them, through the fields without -- the loop's own bookkeeping is pinned
+PRODUCT = [p for p in PLANES if p not in ("steps_primary", "steps_total")]
 
 
-def _render(vrt, engine, sc, st, push, fast):
+def _render(vrt, engine, sc, st, push, fast, planes=PLANES):
     W, H = st.renderResolution()
-    gb = vrt.GeometryBuffer(engine, W, H, PLANES)
+    gb = vrt.GeometryBuffer(engine, W, H, planes)
     stc, fr = st.to_c(), gb.to_c()
     import ctypes as C
     old = os.environ.get("VRT_FAST_LOOP")
@@ -42,6 +45,9 @@ def _check(vrt, oracle, engine, vol, pal, st, push, sky=None, noise=None):
     bad = compare_planes(fast, exp, PLANES)
     assert not bad, ("fast vs oracle", bad)
     assert not compare_planes(slow, exp, PLANES), "general kernel vs oracle"
+    for f in (True, False):
+        bad = compare_planes(_render(vrt, engine, sc, st, push, f, PRODUCT), exp, PRODUCT)
+        assert not bad, ("open cells, fast loop" if f else "open cells, general loop", bad)
     sc.destroy()
     return exp
 
@@ -167,4 +173,6 @@ def test_fast_loop_random_sweep(vrt, oracle, engine):
         exp = oracle.render(oracle.OracleScene(vol, metallic_palette(vrt), sky=sky, noise=noise), push, oracle.params_from(st.to_c()), planes=PLANES, nthreads=8)
         bad = compare_planes(fast, exp, PLANES)
         assert not bad, (case, kind, vol.shape, res, st.traceSettings.maxRaySteps, pos, yaw, pitch, bad[:2])
+        bad = compare_planes(_render(vrt, engine, sc, st, push, True, PRODUCT), exp, PRODUCT)            # the product march: open cells
+        assert not bad, ("open cells", case, kind, vol.shape, res, st.traceSettings.maxRaySteps, pos, yaw, pitch, bad[:2])
         sc.destroy()

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,12 @@ struct vrt_scene {
     uint8_t* vox = nullptr;
     uint64_t *occ1 = nullptr, *occ2 = nullptr, *occ3 = nullptr;
     uint8_t* df = nullptr;
+    // the clearance fields once more without open cells (launch_open_cells): the march the count planes are rendered with,
+    // built when a launch first asks for them
+    uint8_t* df_counts = nullptr;
+    bool open_cells = false;
+    size_t df_bytes = 0;
+    std::mutex lazy;
     vrt_material* palette = nullptr;
     float* sky = nullptr;
     uint8_t* noise = nullptr;
@@ -211,6 +218,7 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->occ2) hipFree(s->occ2);
     if (s->occ3) hipFree(s->occ3);
     if (s->df) hipFree(s->df);
+    if (s->df_counts) hipFree(s->df_counts);
     if (s->palette) hipFree(s->palette);
     if (s->sky) hipFree(s->sky);
     if (s->noise) hipFree(s->noise);
@@ -255,6 +263,55 @@ int vrt_scene_set_blue_noise(vrt_ctx* c, vrt_scene* s, const uint8_t* rgba8, uin
     return VRT_OK;
 }
 
+} // extern "C"
+
+// The clearance fields of a dense scene into dst (df_bytes: eight fields, or nine and the 0xFF byte in trace_df_fast's layout),
+// from the voxels already on the device; open: with the open cells coded 0 (launch_open_cells).  Returns when they are built.
+static hipError_t build_fields(vrt_ctx* c, const vrt_scene* s, uint8_t* dst, bool open)
+{
+    const VolumeView& d = s->d.vol;
+    const size_t nvox = (size_t)d.W * (size_t)d.H * (size_t)d.D, ndf = df_field_bytes(d.W, d.H, d.D);
+    hipError_t e = hipMemsetAsync(dst, 0, s->df_bytes, c->stream);
+    if (e != hipSuccess) return e;
+    if (d.df_fast) {
+        if ((e = hipMemsetAsync(dst + 9 * ndf, 0xFF, 1, c->stream)) != hipSuccess) return e;
+        if ((e = launch_pad_vox(s->vox, d.W, d.H, d.D, dst + 8 * ndf, c->stream)) != hipSuccess) return e;
+    }
+    uint8_t *tmp0 = nullptr, *tmp1 = nullptr;                   // ping-pong buffers of the 3-pass transforms
+    if ((e = hipMalloc((void**)&tmp0, nvox)) != hipSuccess) return e;
+    e = hipMalloc((void**)&tmp1, nvox);
+    if (e == hipSuccess) e = launch_build_df(s->vox, d.W, d.H, d.D, dst, ndf, tmp0, tmp1, c->stream);
+    if (e == hipSuccess && open) e = launch_open_cells(s->vox, d.W, d.H, d.D, dst, ndf, tmp0, tmp1, c->stream);
+    const hipError_t sync = hipStreamSynchronize(c->stream);
+    hipFree(tmp0); if (tmp1) hipFree(tmp1);
+    return e != hipSuccess ? e : sync;
+}
+
+// The fields a launch that writes count planes marches through (no open cells: the iterations of the reference's loop, to the
+// wall), built on first use.
+static int fields_for_counts(vrt_ctx* c, const vrt_scene* cs, const uint8_t** out)
+{
+    vrt_scene* s = const_cast<vrt_scene*>(cs);
+    std::lock_guard<std::mutex> lock(s->lazy);
+    if (!s->open_cells) { *out = s->df; return VRT_OK; }
+    if (!s->df_counts) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)s->df_bytes + 2ull * (uint64_t)s->d.vol.W * s->d.vol.H * s->d.vol.D > (uint64_t)free_b)
+            return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: the count planes (steps_primary, steps_total) need a second set of clearance fields (" +
+                        std::to_string((uint64_t)s->df_bytes) + " bytes), which does not fit the device memory that is free");
+        uint8_t* p = nullptr;
+        HIPCHK(hipMalloc((void**)&p, s->df_bytes));
+        hipError_t e = build_fields(c, s, p, false);
+        if (e != hipSuccess) { hipFree(p); return fail(VRT_ERR_HIP, std::string("building the count planes' clearance fields: ") + hipGetErrorString(e)); }
+        s->df_counts = p;
+        s->bytes += s->df_bytes;
+    }
+    *out = s->df_counts;
+    return VRT_OK;
+}
+
+extern "C" {
+
 int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t H, uint32_t D,
                          const vrt_material palette[256], vrt_scene** out)
 {
@@ -298,9 +355,8 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
         const bool fast = 9ull * ndf + 256ull <= 0xFFFFFFFFull && ((uint64_t)W + 2u) * ((uint64_t)H + 2u) < (1ull << 23);
         const size_t bytes = fast ? 9 * ndf + 256 : 8 * ndf;
         SCHK(hipMalloc((void**)&s->df, bytes));
+        s->df_bytes = bytes;
         s->bytes = (uint64_t)nvox + bytes + (n1 + n2pad + n3pad) * 8ull + 256 * sizeof(vrt_material);
-        SCHK(hipMemsetAsync(s->df, 0, bytes, c->stream));
-        if (fast) SCHK(hipMemsetAsync(s->df + 9 * ndf, 0xFF, 1, c->stream));
         d.df_fast = fast ? 1u : 0u;
     }
     SCHK(hipMemsetAsync(s->occ2, 0, n2pad * 8, c->stream));
@@ -308,15 +364,10 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     SCHK(hipMemcpyAsync(s->vox, voxels, nvox, hipMemcpyHostToDevice, c->stream));
     SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_build_pyramid(s->vox, d.W, d.H, d.D, s->occ1, s->occ2, s->occ3, c->stream));
-    if (d.df_fast) SCHK(launch_pad_vox(s->vox, d.W, d.H, d.D, s->df + 8 * ndf, c->stream));
     {
-        uint8_t *tmp0 = nullptr, *tmp1 = nullptr;               // ping-pong buffers of the 3-pass transforms
-        SCHK(hipMalloc((void**)&tmp0, nvox));
-        hipError_t tmp1_alloc = hipMalloc((void**)&tmp1, nvox);
-        hipError_t df_launch = tmp1_alloc == hipSuccess ? launch_build_df(s->vox, d.W, d.H, d.D, s->df, ndf, tmp0, tmp1, c->stream) : tmp1_alloc;
-        hipError_t df_sync = hipStreamSynchronize(c->stream);
-        hipFree(tmp0); if (tmp1) hipFree(tmp1);
-        SCHK(df_launch); SCHK(df_sync);
+        const char* e = getenv("VRT_OPEN_CELLS");                          // development switch: 0 = fields without open cells
+        s->open_cells = !(e && e[0] == '0');
+        SCHK(build_fields(c, s, s->df, s->open_cells));
     }
 #undef SCHK
     d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.df = s->df; d.df_stride = ndf; s->d.palette = s->palette;
@@ -685,6 +736,18 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     memset(&p, 0, sizeof p);
     p.sc = s->d; p.st = *st;
     if (s->bricks) p.st.traversal = VRT_TRAVERSAL_BRICK;
+    // a launch that writes count planes reports the iterations of the reference's loop: it marches through the fields without
+    // open cells (with the development flags the planes hold the product march's own counters instead)
+    if (!s->bricks && s->open_cells && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u))) {
+        bool counts = false;
+        for (int f = 0; f < n && !counts; f++) counts = frames[f].steps_primary != nullptr || frames[f].steps_total != nullptr;
+        if (counts) {
+            const uint8_t* fields = nullptr;
+            int frc = fields_for_counts(c, s, &fields);
+            if (frc != VRT_OK) return frc;
+            p.sc.vol.df = fields;
+        }
+    }
     p.n_frames = n; p.W = W; p.H = H;
     if (c->div_w != W || c->div_h != H) { c->div_ok = (screen_div_exact(W) && screen_div_exact(H)) ? 1 : 0; c->div_w = W; c->div_h = H; }
     p.rcp_w = 1.0f / (float)W; p.rcp_h = 1.0f / (float)H; p.fast_screen_div = c->div_ok;

@@ -136,6 +136,68 @@ hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df,
 }
 
 // ---------------------------------------------------------------------------------------------
+// open cells.  A ray only ever moves towards the signs of its direction, so from voxel p it can only meet voxels of the box
+// between p and the volume's corner in its octant.  Where that whole box is empty the ray is a miss, whatever it would still
+// walk through: the octant's field holds 0 there -- the code of "the march ends here", as at a solid voxel and in the border;
+// the voxel id read at the same index (0) then says miss.  Hits are untouched (a ray that hits never stands on such a cell);
+// what a miss leaves behind does not depend on where it left the volume (traceRay, frag:176-196: material, position and
+// normal of a miss are 0) -- only the NUMBER of iterations does, which the count planes report: those are rendered through a
+// copy of the fields without open cells (vrt_api.hip).
+//   open(p) = AND over a, b, c >= 0 of empty(p + (a sx, b sy, c sz)): three one-sided AND scans.
+// ---------------------------------------------------------------------------------------------
+
+// scan along y (axis 1; blockIdx.y = z) or z (axis 2; blockIdx.y = y): one thread per line, x across the threads
+__global__ __launch_bounds__(256) void k_open_scan(const uint8_t* __restrict__ vox, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                   int W, int H, int D, int axis, int dir)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (x >= W) return;
+    const int len = axis == 1 ? H : D;
+    const size_t step = axis == 1 ? (size_t)W : (size_t)W * (size_t)H;
+    const size_t base = (size_t)x + (axis == 1 ? (size_t)blockIdx.y * (size_t)W * (size_t)H : (size_t)blockIdx.y * (size_t)W);
+    uint8_t flag = 1;
+    for (int t = 0; t < len; t++) {                            // from the far end of the line towards the near one
+        const size_t i = base + (size_t)(dir > 0 ? len - 1 - t : t) * step;
+        flag &= src ? src[i] : (uint8_t)(vox[i] == 0);
+        dst[i] = flag;
+    }
+}
+
+// scan along x, one wave per line, and the result: 0 into the octant's zero-bordered field where the cell is open
+__global__ __launch_bounds__(256) void k_open_x(const uint8_t* __restrict__ src, uint8_t* __restrict__ field, int W, int H, int D, int dir)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const size_t line = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (line >= (size_t)H * (size_t)D) return;                 // wave-uniform
+    const int y = (int)(line % (size_t)H), z = (int)(line / (size_t)H);
+    const uint8_t* row = src + line * (size_t)W;
+    uint8_t* out = field + 1 + ((size_t)(y + 1) + (size_t)(z + 1) * ((size_t)H + 2u)) * ((size_t)W + 2u);
+    bool carry = true;
+    const int chunks = (W + 63) / 64;
+    for (int c = 0; c < chunks; c++) {
+        const int x = (dir > 0 ? chunks - 1 - c : c) * 64 + lane;
+        const bool f = x < W ? row[x] != 0 : true;
+        const uint64_t blocked = ~__ballot(f);
+        const bool open = carry && f && (dir > 0 ? (blocked >> lane) == 0ull : (blocked << (63 - lane)) == 0ull);
+        if (x < W && open) out[x] = 0;
+        carry = carry && blocked == 0ull;
+    }
+}
+
+hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s)
+{
+    const unsigned bx = (unsigned)((W + 255) / 256);
+    const size_t lines = (size_t)H * (size_t)D;
+    for (int o = 0; o < 8; o++) {
+        const int sx = (o & 1) ? 1 : -1, sy = (o & 2) ? 1 : -1, sz = (o & 4) ? 1 : -1;
+        hipLaunchKernelGGL(k_open_scan, dim3(bx, (unsigned)D), dim3(256), 0, s, vox, (const uint8_t*)nullptr, tmp0, W, H, D, 1, sy);
+        hipLaunchKernelGGL(k_open_scan, dim3(bx, (unsigned)H), dim3(256), 0, s, vox, (const uint8_t*)tmp0, tmp1, W, H, D, 2, sz);
+        hipLaunchKernelGGL(k_open_x, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, s, (const uint8_t*)tmp1, df + (size_t)o * stride, W, H, D, sx);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // brick scenes (vrt_scene_from_bricks): padded pointer grid, brick occupancy, per-voxel clearance of the occupied bricks
 // ---------------------------------------------------------------------------------------------
 

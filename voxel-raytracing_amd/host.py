@@ -483,6 +483,10 @@ _PLANE_SPECS = {
 }
 GBUFFER_PLANES = ("color8", "depth", "motion", "mask8", "position", "normal8")
 DEBUG_PLANES = ("color_f", "hit_id", "hit_voxel", "hit_mask", "steps_primary", "steps_total", "rays_total")
+# Planes whose presence changes which march a launch runs: the count planes select the clearance fields without open cells
+# (the iterations of the reference's loop), hit_voxel the look-up loop that keeps mapPos.  A stage with debug planes renders
+# them in a launch of their own, so that every other plane comes from the march a caller without debug planes gets.
+DIAGNOSTIC_MARCH_PLANES = ("hit_voxel", "steps_primary", "steps_total")
 
 
 class GeometryBuffer:
@@ -505,12 +509,20 @@ class GeometryBuffer:
             return planes[n2]
         raise AttributeError(n)
 
-    def to_c(self) -> _capi.Frame:
+    def to_c(self, only=None, without=()) -> _capi.Frame:
         f = _capi.Frame()
         for n in _capi.FRAME_PLANES:
             t = self.planes.get(n)
+            if (only is not None and n not in only) or n in without:
+                t = None
             setattr(f, n, t.data_ptr() if t is not None else None)
         return f
+
+    def to_c_split(self):
+        """[frame of the product march, frame of the diagnostic march or None] (DIAGNOSTIC_MARCH_PLANES)."""
+        if not any(n in self.planes for n in DIAGNOSTIC_MARCH_PLANES):
+            return [self.to_c(), None]
+        return [self.to_c(without=DIAGNOSTIC_MARCH_PLANES), self.to_c(only=DIAGNOSTIC_MARCH_PLANES)]
 
     def numpy(self):
         return {n: t.cpu().numpy() for n, t in self.planes.items()}
@@ -543,26 +555,29 @@ class GeometryStage:
     def record(self, push: _capi.Push, shard: Optional[_capi.Shard] = None) -> GeometryBuffer:
         gb = self._targets()
         st = self._settings.to_c()
-        fr = gb.to_c()
-        check(lib().vrt_render_geometry(self.engine.ctx, self._scene.handle, C.byref(push), C.byref(st), C.byref(fr),
-                                        C.byref(shard) if shard is not None else None))
+        for fr in gb.to_c_split():
+            if fr is not None:
+                check(lib().vrt_render_geometry(self.engine.ctx, self._scene.handle, C.byref(push), C.byref(st), C.byref(fr),
+                                                C.byref(shard) if shard is not None else None))
         return gb
 
     def prepare(self, shard: Optional[_capi.Shard] = None):
         """Frame loops whose settings do not change between frames: marshal the settings / target structs once and
         return launch(push) -> GeometryBuffer (a Python-side economy only; the same C-ABI call is made)."""
         gb = self._targets()
-        st, fr = self._settings.to_c(), gb.to_c()
+        st, fr, fr_diag = self._settings.to_c(), *gb.to_c_split()
         fn, ctx, scene = lib().vrt_render_geometry, self.engine.ctx, self._scene.handle
         pst, pfr = C.byref(st), C.byref(fr)
         psh = C.byref(shard) if shard is not None else None
 
         def launch(push: _capi.Push) -> GeometryBuffer:
             rc = fn(ctx, scene, C.byref(push), pst, pfr, psh)
+            if rc == 0 and fr_diag is not None:
+                rc = fn(ctx, scene, C.byref(push), pst, C.byref(fr_diag), psh)
             if rc != 0:
                 check(rc)
             return gb
-        launch._keepalive = (st, fr, shard, gb)
+        launch._keepalive = (st, fr, fr_diag, shard, gb)
         return launch
 
     def prepare_batch(self, n: int, shard: Optional[_capi.Shard] = None, shards=None):
@@ -573,7 +588,9 @@ class GeometryStage:
         planes = GBUFFER_PLANES + (DEBUG_PLANES if self._debug else ())
         gbs = [GeometryBuffer(self.engine, W, H, planes) for _ in range(int(n))]
         st = self._settings.to_c()
-        frs = (_capi.Frame * int(n))(*[g.to_c() for g in gbs])
+        split = [g.to_c_split() for g in gbs]
+        frs = (_capi.Frame * int(n))(*[sp[0] for sp in split])
+        frs_diag = (_capi.Frame * int(n))(*[sp[1] for sp in split]) if split and split[0][1] is not None else None
         arr = (_capi.Push * int(n))()
         fn, ctx, scene = lib().vrt_render_geometry_batch, self.engine.ctx, self._scene.handle
         pst = C.byref(st)
@@ -590,10 +607,12 @@ class GeometryStage:
             for k, p in enumerate(pushes):
                 arr[k] = p
             rc = fn(ctx, scene, len(pushes), arr, pst, frs if frames is None else frames, psh)
+            if rc == 0 and frs_diag is not None and frames is None:
+                rc = fn(ctx, scene, len(pushes), arr, pst, frs_diag, psh)
             if rc != 0:
                 check(rc)
             return gbs[:len(pushes)]
-        launch._keepalive = (st, frs, arr, shard, gbs)
+        launch._keepalive = (st, frs, arr, shard, gbs, frs_diag)
         return launch
 
     def record_batch(self, pushes, shard: Optional[_capi.Shard] = None) -> list:
