@@ -1,0 +1,134 @@
+"""Tile tags (k_tile_tags: the 8x8-pixel blocks no occupied 4^3 cell projects onto write what a miss writes without tracing) and
+open cells (a ray ends as a miss where nothing solid is left in its octant): the frames they produce against the frames
+without either (VRT_TILE_TAGS=0 at launch, VRT_OPEN_CELLS=0 at scene build) and against the oracle -- every traversal mode
+(8x8 and 16x16 workgroup tiles), cameras at all kinds of angles and distances, jitter, ragged sizes, batches in kernel
+arguments and in the table, sharded launches, split kernels -- and a check that blocks really are skipped."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import camera_push, compare_planes, metallic_palette
+
+pytestmark = pytest.mark.gpu
+
+GB = ["color8", "depth", "motion", "mask8", "position", "normal8"]
+PRODUCT = GB + ["color_f", "hit_id", "hit_mask", "rays_total"]
+
+
+class _env:
+    def __init__(self, **kv): self.kv = kv
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def _render(vrt, engine, sc, st, push, tags, planes=PRODUCT, shard=None, flags=None):
+    W, H = st.renderResolution()
+    gb = vrt.GeometryBuffer(engine, W, H, planes)
+    stc, fr = st.to_c(), gb.to_c()
+    if flags is not None:
+        stc.flags = flags
+    with _env(VRT_TILE_TAGS="1" if tags else "0"):
+        vrt._capi.check(vrt.lib().vrt_render_geometry(engine.ctx, sc.handle, C.byref(push), C.byref(stc), C.byref(fr),
+                                                      C.byref(shard) if shard is not None else None))
+        engine.synchronize()
+    return gb.numpy()
+
+
+CAMERAS = [  # position in units of the volume's size, yaw, pitch
+    ((0.5, 0.5, -0.8), 90.0, 0.0), ((0.15, 0.8, -0.25), 70.0, -25.0), ((1.2, 1.2, 1.2), 225.0, -35.0), ((0.5, 1.2, 0.5), 90.0, -89.0),
+    ((-0.03, 0.5, 0.4), 10.0, 5.0), ((2.4, 0.55, -2.0), 128.0, -3.0), ((0.5, 0.5, -0.05), 90.0, 0.0), ((0.5, -0.6, 0.5), 90.0, 80.0),
+    ((-0.5, 0.3, 0.5), 200.0, 0.0), ((1.02, 1.02, -0.02), 135.0, -20.0), ((0.5, 0.5, -6.0), 90.0, 0.0),
+]
+
+
+@pytest.mark.parametrize("trav", ["AUTO", "DF", "DENSE", "BITMASK", "JUMP", "DFJ"])
+def test_tags_and_open_cells_change_nothing(vrt, oracle, engine, trav):
+    rng = np.random.default_rng(11)
+    vols = [vrt.synthetic.treehouse(48, seed=4), vrt.synthetic.floating_cubes(40, seed=8, count=25),
+            (rng.random((36, 20, 52)) < 0.004).astype(np.uint8) * np.uint8(77)]
+    for vi, vol in enumerate(vols):
+        D, H, W = vol.shape
+        pal = metallic_palette(vrt)
+        sky, noise = vrt.synthetic.sky_gradient(32, 16), vrt.synthetic.blue_noise_standin(32)
+        with _env(VRT_OPEN_CELLS="0"):
+            closed = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
+        sc = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
+        osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
+        for ci, (p, yaw, pitch) in enumerate(CAMERAS):
+            res = [(96, 64), (131, 77), (64, 40)][(ci + vi) % 3]
+            st = vrt.VoxelRenderSettings.primary_only(res, getattr(vrt, "TRAVERSAL_" + trav))
+            if (ci + vi) % 2:
+                st.occlusionSettings.numSamples = 2; st.traceSettings.shadows = True; st.traceSettings.maxReflections = 2
+                st.traceSettings.splitKernels = ci % 4 == 1
+            push = camera_push(vrt, (W, H, D), res, pos=(p[0] * W, p[1] * H, p[2] * D), yaw=yaw, pitch=pitch, frame=ci,
+                               jitter=(0.3, -0.2) if ci % 3 == 0 else (0.0, 0.0))
+            ref = _render(vrt, engine, closed, st, push, False)
+            for name, scene, tags in (("open cells", sc, False), ("open cells + tile tags", sc, True), ("tile tags", closed, True)):
+                bad = compare_planes(_render(vrt, engine, scene, st, push, tags), ref, PRODUCT)
+                assert not bad, (name, trav, vi, ci, bad[:2])
+            if ci % 4 == 0:
+                exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=PRODUCT, nthreads=8)
+                assert not compare_planes(ref, exp, PRODUCT), ("oracle", trav, vi, ci)
+        sc.destroy(); closed.destroy()
+
+
+def test_tags_skip_blocks_and_open_cells_end_rays(vrt, engine):
+    """The development counters (VRT_FLAG_DEBUG_PLANES: steps_primary = iterations the product march took) show the work
+    going away: fewer iterations with open cells, fewer again with tags, the same hits."""
+    vol = vrt.synthetic.treehouse(64, seed=2)
+    res = (160, 96)
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    push = camera_push(vrt, (64, 64, 64), res)
+    with _env(VRT_OPEN_CELLS="0"):
+        closed = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt))
+    sc = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt))
+    planes = ["hit_id", "steps_primary", "steps_total", "rays_total"]
+    a = _render(vrt, engine, closed, st, push, False, planes, flags=1)
+    b = _render(vrt, engine, sc, st, push, False, planes, flags=1)
+    c = _render(vrt, engine, sc, st, push, True, planes, flags=1)
+    assert (a["hit_id"] == b["hit_id"]).all() and (a["hit_id"] == c["hit_id"]).all()
+    sa, sb, scount = (int(x["steps_primary"].astype(np.int64).sum()) for x in (a, b, c))
+    assert sb < 0.9 * sa and scount < 0.98 * sb, (sa, sb, scount)
+    # the count planes of an ordinary launch still report the reference's iterations, whatever the scene was built with
+    d = _render(vrt, engine, sc, st, push, True, planes)
+    e = _render(vrt, engine, closed, st, push, False, planes)
+    assert (d["steps_primary"] == e["steps_primary"]).all() and (d["steps_total"] == e["steps_total"]).all()
+    sc.destroy(); closed.destroy()
+
+
+@pytest.mark.parametrize("nranks,strip_rows", [(1, 16), (3, 16), (2, 32)])
+def test_tags_in_batches_and_sharded_launches(vrt, engine, nranks, strip_rows):
+    vol = vrt.synthetic.floating_cubes(48, seed=5, count=30)
+    sc = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt), sky=vrt.synthetic.sky_gradient(32, 16))
+    res = (120, 100)
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    for n in (3, 11):                                              # slots in the kernel arguments / in the device table
+        pushes = [camera_push(vrt, (48, 48, 48), res, pos=(24.0 + 3.0 * k, 20.0 + k, -50.0 + 4.0 * k), yaw=90.0 - 4.0 * k, pitch=2.0 * k)
+                  for k in range(n)]
+        got = {}
+        for tags in (False, True):
+            frames = [np.zeros((res[1], res[0], 4), np.uint8) for _ in range(n)]
+            with _env(VRT_TILE_TAGS="1" if tags else "0"):
+                for rank in range(nranks):
+                    stage = vrt.GeometryStage(engine, st, sc)
+                    gbs = stage.prepare_batch(n, vrt.make_shard(rank, nranks, strip_rows))(pushes)
+                    engine.synchronize()
+                    rows = vrt.distributed.packed_row_map(res[1], rank, nranks, strip_rows)
+                    rows = rows[rows >= 0]
+                    for k in range(n):
+                        frames[k][rows] = gbs[k].color.cpu().numpy()[rows]
+            got[tags] = frames
+        for k in range(n):
+            assert (got[True][k] == got[False][k]).all(), (n, k)
+            single = _render(vrt, engine, sc, st, pushes[k], False, ["color8"])["color8"]
+            assert (got[True][k] == single).all(), (n, k)
+    sc.destroy()

@@ -29,3 +29,5 @@ for t in (0.0, 4.0, 7.75):
           f"(all 64 lanes hit: {int((wh == 64).sum())}, no lane hits: {int((geo & (wh == 0)).sum())}, mixed: {int((geo & (wh > 0) & (wh < 64)).sum())})")
     print(f"   look-ups (loop trips) total {int(wo[geo].sum())} = {wo[geo].mean():.1f} per geometry wave; "
           f"wave-iterations total {int(ws.sum())} = {ws[geo].mean():.1f} per geometry wave; lane-steps {int(steps.sum())}")
+    nh = geo & (wh == 0)
+    print(f"   of which in waves without a hit: look-ups {int(wo[nh].sum())}, wave-iterations {int(ws[nh].sum())}; all-hit waves: {int(wo[wh == 64].sum())}, {int(ws[wh == 64].sum())}")

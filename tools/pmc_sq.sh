@@ -16,5 +16,5 @@ for r in csv.DictReader(open(f)):
     if "k_primary" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
-    print(f"{k:24s} {sum(v)/len(v)/32/1e6:10.3f} M per frame  ({len(v)} launches)")
+    print(f"{k:24s} {sum(v)/len(v)/64/1e6:10.3f} M per frame  ({len(v)} launches)")
 PY

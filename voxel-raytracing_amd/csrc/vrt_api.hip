@@ -58,6 +58,10 @@ struct vrt_ctx {
     bool tab_busy[kTabRing] = {false, false, false, false};
     int tab_next = 0;
     hipStream_t upload_stream = nullptr;
+    // tile tags of the latest launch (k_tile_tags): one word per 8x8-pixel block and frame, valid where == tile_gen
+    uint32_t* tile_tags = nullptr;
+    size_t tile_tags_words = 0;
+    uint32_t tile_gen = 0;
 };
 
 struct vrt_scene {
@@ -68,6 +72,9 @@ struct vrt_scene {
     // the clearance fields once more without open cells (launch_open_cells): the march the count planes are rendered with,
     // built when a launch first asks for them
     uint8_t* df_counts = nullptr;
+    uint32_t* cells = nullptr;         // occupied 4^3 cells (k_tile_tags), x | y << 10 | z << 20
+    uint32_t n_cells = 0;
+    bool cells_ok = false;
     bool open_cells = false;
     size_t df_bytes = 0;
     std::mutex lazy;
@@ -112,6 +119,7 @@ void vrt_ctx_destroy(vrt_ctx* c)
     hipStreamSynchronize(c->stream);
     if (c->records) hipFree(c->records);
     if (c->hit_list) hipFree(c->hit_list);
+    if (c->tile_tags) hipFree(c->tile_tags);
     if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
     for (int i = 0; i < vrt_ctx::kTabRing; i++) {
         if (c->tab_dev[i]) hipFree(c->tab_dev[i]);
@@ -219,6 +227,7 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->occ3) hipFree(s->occ3);
     if (s->df) hipFree(s->df);
     if (s->df_counts) hipFree(s->df_counts);
+    if (s->cells) hipFree(s->cells);
     if (s->palette) hipFree(s->palette);
     if (s->sky) hipFree(s->sky);
     if (s->noise) hipFree(s->noise);
@@ -364,6 +373,29 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     SCHK(hipMemcpyAsync(s->vox, voxels, nvox, hipMemcpyHostToDevice, c->stream));
     SCHK(hipMemcpyAsync(s->palette, palette, 256 * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_build_pyramid(s->vox, d.W, d.H, d.D, s->occ1, s->occ2, s->occ3, c->stream));
+    // the occupied 4^3 cells as a list (from the 16^3 summaries: one bit per cell), for the tile tags of a launch
+    if (d.n1x <= 1024 && d.n1y <= 1024 && d.n1z <= 1024) {
+        std::vector<uint64_t> h2(n2);
+        SCHK(hipMemcpyAsync(h2.data(), s->occ2, n2 * 8, hipMemcpyDeviceToHost, c->stream));
+        SCHK(hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> cells;
+        for (size_t w = 0; w < n2; w++) {
+            uint64_t bits = h2[w];
+            if (!bits) continue;
+            const uint32_t wx = (uint32_t)(w % (size_t)d.n2x), wy = (uint32_t)((w / (size_t)d.n2x) % (size_t)d.n2y), wz = (uint32_t)(w / ((size_t)d.n2x * d.n2y));
+            for (uint32_t b = 0; b < 64; b++)
+                if ((bits >> b) & 1ull) cells.push_back((wx * 4u + (b & 3u)) | ((wy * 4u + ((b >> 2) & 3u)) << 10) | ((wz * 4u + (b >> 4)) << 20));
+        }
+        if (cells.size() <= (4u << 20)) {                                   // (beyond that the tags cost more than they save)
+            if (!cells.empty()) {
+                SCHK(hipMalloc((void**)&s->cells, cells.size() * 4));
+                SCHK(hipMemcpy(s->cells, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
+                s->bytes += cells.size() * 4;
+            }
+            s->n_cells = (uint32_t)cells.size();
+            s->cells_ok = true;
+        }
+    }
     {
         const char* e = getenv("VRT_OPEN_CELLS");                          // development switch: 0 = fields without open cells
         s->open_cells = !(e && e[0] == '0');
@@ -738,9 +770,10 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     if (s->bricks) p.st.traversal = VRT_TRAVERSAL_BRICK;
     // a launch that writes count planes reports the iterations of the reference's loop: it marches through the fields without
     // open cells (with the development flags the planes hold the product march's own counters instead)
-    if (!s->bricks && s->open_cells && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u))) {
-        bool counts = false;
+    bool counts = false;
+    if (!(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)))
         for (int f = 0; f < n && !counts; f++) counts = frames[f].steps_primary != nullptr || frames[f].steps_total != nullptr;
+    if (!s->bricks && s->open_cells) {
         if (counts) {
             const uint8_t* fields = nullptr;
             int frc = fields_for_counts(c, s, &fields);
@@ -858,6 +891,42 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         HIPCHK(hipStreamWaitEvent(c->stream, c->tab_uploaded[tab], 0));
     }
     if (c->timing) HIPCHK(hipEventRecord(c->ev_geo0, c->stream));
+    // tile tags: dense scenes, frames with a box rectangle, launches that do not report the reference's iteration counts
+    {
+        const char* e = getenv("VRT_TILE_TAGS");                          // development switch: 0 = off
+        bool want = !(e && e[0] == '0') && !s->bricks && s->cells_ok && !counts && W <= 8128 && H <= 8128;
+        bool any = false;
+        for (int f = 0; f < n && want && !any; f++) any = !(slots[f].box[0] == 0 && slots[f].box[1] == 255 && slots[f].box[2] == 0 && slots[f].box[3] == 255);
+        const bool tags = want && any;
+        {
+            // (in the launch's local rows of 8x8 blocks: vrt_device.hip k_tile_tags)
+            p.tags_x = tags ? (uint32_t)(p.tiles_x * (p.tile_w / 8)) : 0u; p.tags_y = tags ? (uint32_t)(p.tiles_y_local * (p.tile_h / 8)) : 0u;
+            p.tags_per_frame = p.tags_x * p.tags_y + 1u;
+            // (without tags: one word per frame that says "trace every block")
+            const size_t words = (size_t)p.tags_per_frame * (size_t)n;
+            if (c->tile_tags_words < words) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->tile_tags) hipFree(c->tile_tags);
+                c->tile_tags = nullptr; c->tile_tags_words = 0;
+                HIPCHK(hipMalloc((void**)&c->tile_tags, words * sizeof(uint32_t)));
+                HIPCHK(hipMemsetAsync(c->tile_tags, 0, words * sizeof(uint32_t), c->stream));
+                c->tile_tags_words = words;
+            }
+            if (++c->tile_gen == 0u) {                                    // (wrapped: stale tags could match again)
+                HIPCHK(hipMemsetAsync(c->tile_tags, 0, c->tile_tags_words * sizeof(uint32_t), c->stream));
+                c->tile_gen = 1u;
+            }
+            p.tile_tags = c->tile_tags; p.tile_gen = c->tile_gen;
+            if (tags) {
+                p.cells = s->cells; p.n_cells = s->n_cells;
+                HIPCHK(launch_tile_tags(p, c->stream));
+            } else {
+                // every frame's one word = tile_gen
+                std::vector<uint32_t> ones((size_t)n, c->tile_gen);
+                HIPCHK(hipMemcpyAsync(c->tile_tags, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            }
+        }
+    }
     HIPCHK(launch_primary(p, c->stream));
     if (tab >= 0) { HIPCHK(hipEventRecord(c->tab_consumed[tab], c->stream)); c->tab_busy[tab] = true; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev_prim1, c->stream));

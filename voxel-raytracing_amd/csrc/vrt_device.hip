@@ -758,6 +758,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     int x0, y0, yp0, ty, tx;
     uint32_t frame;
     if (!block_to_tile(M, frame, ty, tx)) return;                        // uniform per workgroup
+    // the block's tile tag (k_tile_tags) and the frame's "the tags say nothing" word: two scalar loads that leave together with
+    // the frame slot's (their address needs nothing from the slot: tags are laid out in the launch's LOCAL rows of 8x8 blocks,
+    // in dispatch order), looked at after ray generation.  Written by the kernel before this one: constant address space.
+    // (A launch without tags points at one word per frame that holds its tile_gen, with tags_x = 0 and tags_per_frame = 1.)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t tile_gen = P.tile_gen;
+    uint32_t tag, tag_all;
+    {
+        const_u32_ptr tg = (const_u32_ptr)(P.tile_tags + (size_t)frame * P.tags_per_frame);
+        const uint32_t tags_x = P.tags_x, sh = (uint32_t)M.tile >> 4;
+        const uint32_t row8 = ((uint32_t)ty << sh) + (uint32_t)(wave >> 1), col8 = ((uint32_t)tx << sh) + (uint32_t)(wave & 1);
+        tag = tg[row8 * tags_x + (tags_x ? col8 : 0u)];
+        tag_all = tg[P.tags_per_frame - 1u];
+    }
     // ... and so does the frame's part of ray generation (camera, hoisted constants, strip assignment), in one batch
     RayGenConsts g;
     float cam_pos[3], cam_right[3];
@@ -765,6 +779,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     uint32_t box;
     SlotOf<TABLE>::head(P, frame, g, cam_pos, cam_right, shard_rank, box);
     asm volatile("" : "+s"(box));
+    // (one scalar from here on, not three: past 80 scalar registers a SIMD holds 7 of these waves, not 8)
+    const uint32_t untagged = (uint32_t)__builtin_amdgcn_readfirstlane((tag != tile_gen && tag_all != tile_gen) ? 1 : 0);
     const uint4 boxr = make_uint4(box & 0xFFu, (box >> 8) & 0xFFu, (box >> 16) & 0xFFu, box >> 24);
     float cpx = cam_pos[0], cpy = cam_pos[1], cpz = cam_pos[2];
     float crx = cam_right[0], cry = cam_right[1], crz = cam_right[2];
@@ -783,7 +799,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // wave w -> 8x8 block (w&1, w>>1) of the tile (one-wave workgroups: w = 0); lane -> (l&7, l>>3).
     // (A 16x4 block would make every store of the 4-byte planes a full 64-byte line, but measured 3 % slower:
     // the wider footprint lowers the wave-wide clearance minimum by more than the stores gain.)
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler then knows the block's origin, the rectangle test and the tag test
+    // below are scalar -- a branch, not an EXEC mask around the traversal)
+    int lane = threadIdx.x & 63;
     const int px0 = x0 + (wave & 1) * 8, py0 = y0 + (wave >> 1) * 8;       // the wave's 8x8 block (wave-uniform)
     int px = px0 + (lane & 7);
     int py = py0 + (lane >> 3);
@@ -796,8 +814,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     f3 dir = primary_dir_fast(g, crx, cry, crz, rcp_w, rcp_h, fast_div, px, py);
     RayHit h; RayInt r;
     // a wave whose 8x8 pixels lie outside the frame's box rectangle (FrameSlot::box, vrt_internal.h box_rect) cannot meet the
-    // volume: it writes what a miss writes without testing the box (wave-uniform: the rectangle is in units of 32 pixels)
-    if ((uint32_t)(px0 >> 5) < boxr.x || (uint32_t)(px0 >> 5) >= boxr.y || (uint32_t)(py0 >> 5) < boxr.z || (uint32_t)(py0 >> 5) >= boxr.w) {
+    // volume: it writes what a miss writes without testing the box (wave-uniform: the rectangle is in units of 32 pixels) --
+    // and inside the rectangle neither can a wave whose block no occupied 4^3 cell of the volume projects onto (k_tile_tags)
+    const bool skip = box != 0xFF00FF00u && ((uint32_t)(px0 >> 5) < boxr.x || (uint32_t)(px0 >> 5) >= boxr.y || (uint32_t)(py0 >> 5) < boxr.z ||
+                                             (uint32_t)(py0 >> 5) >= boxr.w || untagged != 0u);
+    if (skip) {
         h.material = 0u; h.dir = dir; h.pos = mk3(0.0f, 0.0f, 0.0f); h.normal = mk3(0.0f, 0.0f, 0.0f); h.ncode = 0xFFFFFFFFu;
         r.material = 0u; r.mask = 0u; r.fetches = 0u; r.mx = r.my = r.mz = 0; r.dbg0 = 1u; r.dbg1 = 0u;
     } else
@@ -921,6 +942,83 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
 // ---------------------------------------------------------------------------------------------
 // launch plumbing for K1 / K2
 // ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
+// Tile tags: which 8x8-pixel blocks of a frame can a primary ray meet anything in?  One lane per occupied 4^3-voxel cell of
+// the volume (the scene's list of them); the cell, grown by one voxel on every side, is projected through the frame's
+// camera and the blocks its screen rectangle (+ 2 pixels) touches are tagged with the launch's generation number -- plain
+// stores of one value, no clearing between launches.  A block without the tag holds no pixel whose ray passes within a
+// voxel of anything solid: its wave writes what a miss writes (k_primary).  Frames without a box rectangle (camera in or
+// near the volume, a degenerate basis) have no tags, nor have frames with a cell closer than the projection can bound.
+// ---------------------------------------------------------------------------------------------
+template <bool TABLE>
+__global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
+{
+    const uint32_t frame = blockIdx.y;
+    RayGenConsts g;
+    float cam[3], U[3];
+    int shard_rank;
+    uint32_t box;
+    SlotOf<TABLE>::head(P, frame, g, cam, U, shard_rank, box);
+    if (box == 0xFF00FF00u) return;
+    const uint32_t ci = blockIdx.x * 256u + threadIdx.x;
+    if (ci >= P.n_cells) return;
+    const uint32_t cell = P.cells[ci];
+    const float lo[3] = {(float)((cell & 1023u) * 4u) - 1.0f, (float)(((cell >> 10) & 1023u) * 4u) - 1.0f, (float)((cell >> 20) * 4u) - 1.0f};
+    uint32_t* tags = P.tile_tags + (size_t)frame * P.tags_per_frame;
+    // ray of screen position (a, b) in [-1, 1]^2: C + a U + b V (frag:312-319); [U V C] (a, b, lambda)^T = p - cam
+    const float V[3] = {g.planeV.x, g.planeV.y, g.planeV.z};
+    const float C[3] = {g.cd.x + g.jx, g.cd.y + g.jy, g.cd.z};
+    const float c0[3] = {V[1] * C[2] - V[2] * C[1], V[2] * C[0] - V[0] * C[2], V[0] * C[1] - V[1] * C[0]};   // V x C
+    const float c1[3] = {C[1] * U[2] - C[2] * U[1], C[2] * U[0] - C[0] * U[2], C[0] * U[1] - C[1] * U[0]};   // C x U
+    const float c2[3] = {U[1] * V[2] - U[2] * V[1], U[2] * V[0] - U[0] * V[2], U[0] * V[1] - U[1] * V[0]};   // U x V
+    const float det = U[0] * c0[0] + U[1] * c0[1] + U[2] * c0[2];
+    const float scale = (fabsf(U[0]) + fabsf(U[1]) + fabsf(U[2])) * (fabsf(V[0]) + fabsf(V[1]) + fabsf(V[2])) * (fabsf(C[0]) + fabsf(C[1]) + fabsf(C[2]));
+    bool all = !(fabsf(det) > 1e-3f * scale);
+    const float rdet = 1.0f / det;
+    float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
+    for (int k = 0; k < 8; k++) {
+        const float p[3] = {lo[0] + ((k & 1) ? 6.0f : 0.0f) - cam[0], lo[1] + ((k & 2) ? 6.0f : 0.0f) - cam[1], lo[2] + ((k & 4) ? 6.0f : 0.0f) - cam[2]};
+        const float a = (p[0] * c0[0] + p[1] * c0[1] + p[2] * c0[2]) * rdet, b = (p[0] * c1[0] + p[1] * c1[1] + p[2] * c1[2]) * rdet;
+        const float lam = (p[0] * c2[0] + p[1] * c2[1] + p[2] * c2[2]) * rdet;
+        const float reach = fabsf(p[0]) + fabsf(p[1]) + fabsf(p[2]);
+        if (!(lam > 0.05f * reach)) all = true;               // behind the camera plane, or at a grazing angle to it
+        const float rl = __builtin_amdgcn_rcpf(lam);          // (1 ulp: the rectangle has two pixels of margin)
+        const float fx = (a * rl + 1.0f) * 0.5f * g.W, fy = (b * rl + 1.0f) * 0.5f * g.H;
+        x0 = fminf(x0, fx); x1 = fmaxf(x1, fx); y0 = fminf(y0, fy); y1 = fmaxf(y1, fy);
+    }
+    if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) all = true;
+    const float m = 2.0f;
+    int tx0 = (int)floorf(fmaxf(x0 - m, 0.0f) * 0.125f), tx1 = (int)floorf(fminf(x1 + m, g.W - 1.0f) * 0.125f);
+    int ty0 = (int)floorf(fmaxf(y0 - m, 0.0f) * 0.125f), ty1 = (int)floorf(fminf(y1 + m, g.H - 1.0f) * 0.125f);
+    if (!all && (x1 + m < 0.0f || y1 + m < 0.0f || x0 - m > g.W || y0 - m > g.H)) return;      // off screen
+    if (!all && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 1024) all = true;                           // too close to bound cheaply
+    if (all) { tags[P.tags_per_frame - 1u] = P.tile_gen; return; }
+    // screen row of blocks -> the row K1 finds it in: the launch's local rows (the strips this frame's rank owns), in dispatch
+    // order (tile_origin: bottom rows first)
+    const int nranks = P.sh.nranks, rows8 = P.sh.strip_rows >> 3, k = P.tile_h >> 3, T = P.tiles_y_local;
+    for (int ty = ty0; ty <= ty1; ty++) {
+        int local = ty;
+        if (nranks > 1) {
+            const int strip = ty / rows8;
+            if (strip % nranks != shard_rank) continue;
+            local = (strip / nranks) * rows8 + (ty - strip * rows8);
+        }
+        const int tyl = local / k;                             // the workgroup tile's local row, and the block's row within the tile
+        if (tyl >= T) continue;
+        const uint32_t row = (uint32_t)((T - 1 - tyl) * k + (local - tyl * k));
+        for (int tx = tx0; tx <= tx1; tx++) tags[row * P.tags_x + (uint32_t)tx] = P.tile_gen;
+    }
+}
+
+hipError_t launch_tile_tags(const GeomParams& p, hipStream_t s)
+{
+    if (p.n_cells == 0u) return hipSuccess;
+    dim3 grid((p.n_cells + 255u) / 256u, (unsigned)p.n_frames), block(256);
+    if (p.table) hipLaunchKernelGGL(k_tile_tags<true>, grid, block, 0, s, p);
+    else         hipLaunchKernelGGL(k_tile_tags<false>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
 
 template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)

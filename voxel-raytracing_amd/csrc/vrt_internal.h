@@ -59,8 +59,9 @@ inline RayGenConsts raygen_consts(const vrt_push& pc)
 // returns the whole screen.
 inline void box_rect(const vrt_push& pc, uint8_t out[4])
 {
-    out[0] = 0; out[1] = 255; out[2] = 0; out[3] = 255;
+    out[0] = 0; out[1] = 255; out[2] = 0; out[3] = 255;       // = "no rectangle": the kernel tests nothing
     const double W = pc.screen_size[0], H = pc.screen_size[1];
+    if (W > 8128.0 || H > 8128.0) return;                     // (a byte counts units of 32 pixels)
     const double dim[3] = {(double)pc.volume_bounds[0], (double)pc.volume_bounds[1], (double)pc.volume_bounds[2]};
     const double cam[3] = {pc.cam_pos[0], pc.cam_pos[1], pc.cam_pos[2]};
     const double m = 1.0;
@@ -175,6 +176,13 @@ struct GeomParams {
     int32_t    fast_loop;      // 1: AUTO / DF run the hand-written look-up loop (trace_df_fast; the host checked its preconditions)
     int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
     uint32_t   occ2_bytes, occ3_bytes;   // both multiples of 16
+    // Tile tags (k_tile_tags, launched ahead of K1): one word per 8x8-pixel block of every frame of the launch, == tile_gen
+    // where a primary ray of the block can meet an occupied 4^3 cell of the volume; word tags_per_frame - 1 of a frame ==
+    // tile_gen: the frame's tags say nothing (trace every block).  nullptr: no tags in this launch.
+    uint32_t*  tile_tags;
+    uint32_t   tile_gen, tags_x, tags_y, tags_per_frame;
+    const uint32_t* cells;     // the scene's occupied 4^3 cells, x | y << 10 | z << 20 (in cells)
+    uint32_t   n_cells;
 };
 
 struct DenoiseParams {
@@ -220,6 +228,7 @@ hipError_t launch_brick_fine(const uint32_t* padded, int pbx, int pby, const uin
                              uint8_t* fine, hipStream_t s);
 hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s);
 hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s);
+hipError_t launch_tile_tags(const GeomParams& p, hipStream_t s);
 hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst, hipStream_t s);
 hipError_t launch_primary(const GeomParams& p, hipStream_t s);
 hipError_t launch_shade(const GeomParams& p, hipStream_t s);

@@ -835,7 +835,16 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
     // scalars of the block: s60 = i (iterations done by every live lane), s61 = kw, s62 = left / iterations still to do,
     // s63 = 0xFF, s[66:67] = saved EXEC; vectors: v48..v50 temporaries, v52 = the byte read = the lane's vote,
     // v53 = index of the byte to read next
+    // the block starts on an instruction-cache line: where its loops fall relative to the lines is then a property of the block,
+    // not of the code the compiler happens to put in front of it (6 % between two builds that differed elsewhere)
+#ifndef VRT_LOOP_PAD_N
+#define VRT_LOOP_PAD_N 0             // s_nop words after the alignment (development: scan of the block's phase)
+#endif
+#define VRT_STR2(x) #x
+#define VRT_STR(x) VRT_STR2(x)
     asm volatile(
+        ".p2align 6\n\t"
+        ".fill " VRT_STR(VRT_LOOP_PAD_N) ", 4, 0xBF800000\n\t"
         "s_mov_b32 s60, 0\n\t"
         "s_movk_i32 s63, 0xff\n\t"
         // the loop runs under the EXEC mask it is entered with (all 64 lanes for primary rays; the hit lanes of a wave for its
