@@ -1026,6 +1026,12 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
         {
             const float log2e = 1.44269504088896341f;
             p.kc = log2e / p.phi_color; p.kp = log2e / p.phi_pos; p.kn = log2e / (p.phi_normal * (p.step_width * p.step_width));   // pass 0: all 0
+            {
+                const float sw2 = p.step_width * p.step_width;
+                auto ok = [](float v) { return v >= 0x1p-20f && v <= 0x1p20f; };
+                p.packed_ok = (ok(p.phi_color) && ok(p.phi_normal) && ok(p.phi_pos) && ok(sw2)) ? 1 : 0;
+                p.rc = 1.0f / p.phi_color; p.rn = 1.0f / p.phi_normal; p.rp = 1.0f / p.phi_pos; p.rs = 1.0f / sw2;
+            }
         }
         p.color_in = last; p.color_out = targets[ping];
         int ext = 0;

@@ -1212,11 +1212,61 @@ __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
     reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ---- the exact weights of TWO taps at a time, without branches -------------------------------------------------------------
+// The weighted pass is bound by instruction issue (two Cephes exponentials and two correctly rounded divisions per channel
+// and tap, behind data-dependent shortcuts whose short EXEC-masked blocks cost as much as they save).  Every shortcut of
+// edge_weight() is the value the long way round gives anyway -- exp_spec(-0) = 1 exactly, a factor 0 makes the product +0 --
+// so the long way round, for two taps at once in the two halves of packed fp32 instructions (v_pk_mul / v_pk_add / v_pk_fma:
+// the same IEEE operations element-wise, never contracted), is the same arithmetic: 12 packed exponentials per pixel
+// instead of 27 scalar ones.
+
+// RN(a / b) element-wise for a pass-uniform b with r = RN(1 / b): q0 = a r and two residual corrections -- the core of the
+// compiler's own IEEE division sequence (which refines an approximate reciprocal to within an ulp, multiplies, and corrects
+// twice), without its range scaling: exact while no intermediate leaves the normal range, i.e. for b in [2^-20, 2^20] (the
+// host checks) and a = 0 or a in [2^-90, 2^90] (the caller checks; decoded 8-bit guides cannot leave it).
+__device__ __forceinline__ v2f div_uniform2(v2f a, float b, float r)
+{
+    const v2f nb = {-b, -b}, rr = {r, r};
+    v2f q = a * rr;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q, a), rr, q);
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q, a), rr, q);
+    return q;
+}
+
+// min(exp_spec(-q), 1) element-wise for q >= 0 (vrt_spec.h exp_spec, operation for operation)
+__device__ __forceinline__ v2f edge_weight2(v2f q)
+{
+    const v2f x0 = -q;
+    const v2f fx = __builtin_elementwise_floor(x0 * 1.44269504088896341f + 0.5f);
+    v2f x = x0 - fx * 0.693359375f;
+    x = x - fx * -2.12194440e-4f;
+    const v2f z = x * x;
+    const v2f p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x
+                     + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * z + x + 1.0f;
+    const int n0 = (int)fx.x, n1 = (int)fx.y;
+    const v2f sc = {__uint_as_float(((uint32_t)n0 + 127u) << 23), __uint_as_float(((uint32_t)n1 + 127u) << 23)};
+    const v2f e = p * sc;
+    v2f w;
+    w.x = x0.x < -87.0f ? 0.0f : fminf(e.x, 1.0f);
+    w.y = x0.y < -87.0f ? 0.0f : fminf(e.y, 1.0f);
+    return w;
+}
+
+// |a - b|^2 in the order of dist2_4, the two halves of each float4 in one packed instruction
+__device__ __forceinline__ float dist2_4pk(const float4& a, const float4& b)
+{
+    const v2f t01 = (v2f){a.x, a.y} - (v2f){b.x, b.y}, t23 = (v2f){a.z, a.w} - (v2f){b.z, b.w};
+    const v2f q01 = t01 * t01, q23 = t23 * t23;
+    return ((q01.x + q01.y) + q23.x) + q23.y;
+}
+
 // LDS-tiled form for integral stepWidth: a workgroup owns 64x4 pixels; the guides of that tile plus a halo of
 // R = stepWidth pixels are fetched, decoded ONCE and parked in LDS as three float4 planes (48 B per pixel), so each
 // pixel's guides are read from HBM/L2 once per pass instead of once per tap that lands on it (9x), and the 8-bit
 // decodes are not repeated per tap.  Same arithmetic on the same decoded values as k_denoise.
-template <bool PHI_INF, bool SHIPPED, bool FAST = false>
+template <bool PHI_INF, bool SHIPPED, bool FAST = false, bool PACKED = false>
 __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int R)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
@@ -1278,6 +1328,58 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
     float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float total = 0.0f;
     const int rowoff = R * RW;
+    if constexpr (PACKED && !PHI_INF && !FAST) {
+        // taps in the shader's order, two at a time; the centre tap (all three distances are 0 or NaN: every weight is 1)
+        // between them where the order has it
+        v2f s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
+        constexpr int npairs = SHIPPED ? 1 : 4;
+#pragma unroll 1
+        for (int j = 0; j < npairs; j++) {
+            int ta, tb; float ka, kb;                          // tap offsets (in units of R, relative to c0) and kernel weights
+            if (SHIPPED) { ta = -rowoff - R; tb = -rowoff + R; ka = kGauss2; kb = kGauss0; }
+            else if (j == 0) { ta = -rowoff - R; tb = -rowoff; ka = kGauss2; kb = kGauss1; }
+            else if (j == 1) { ta = -rowoff + R; tb = -R; ka = kGauss2; kb = kGauss1; }
+            else if (j == 2) { ta = R; tb = rowoff - R; ka = kGauss1; kb = kGauss2; }
+            else { ta = rowoff; tb = rowoff + R; ka = kGauss1; kb = kGauss2; }
+            if (!SHIPPED && j == 2) {                          // tap 4, the centre: w = 1, kern = 1
+                s01 += (v2f){sc.x, sc.y}; s23 += (v2f){sc.z, sc.w};
+                total += 1.0f;
+            }
+            const float4 oca = lc[c0 + ta], ocb = lc[c0 + tb], opa = lp[c0 + ta], opb = lp[c0 + tb], ona = ln[c0 + ta], onb = ln[c0 + tb];
+            const v2f dp = {dist2_4pk(sp, opa), dist2_4pk(sp, opb)};
+            const v2f dc = {dist2_4pk(sc, oca), dist2_4pk(sc, ocb)};
+            const v2f dn = {dist2_4pk(sn, ona), dist2_4pk(sn, onb)};
+            // positions are the caller's floats: a distance outside the range the short division is exact for (tiny, huge,
+            // inf, NaN) sends the wave through edge_weight() for this pair
+            const uint32_t ua = __float_as_uint(dp.x), ub = __float_as_uint(dp.y);
+            const bool odd = (ua != 0u && ua - 0x12800000u > 0x6C800000u - 0x12800000u) || (ub != 0u && ub - 0x12800000u > 0x6C800000u - 0x12800000u);
+            v2f w;
+            if (__builtin_expect(__ballot(odd) != 0ull, 0)) {
+                const float pa = edge_weight(dp.x, P.phi_pos), pb = edge_weight(dp.y, P.phi_pos);
+                float ca = 1.0f, na = 1.0f, cb = 1.0f, nb = 1.0f;
+                if (pa != 0.0f) { ca = edge_weight(dc.x, P.phi_color); na = dn.x == 0.0f ? 1.0f : edge_weight(fmaxf(dn.x / sw2, 0.0f), P.phi_normal); }
+                if (pb != 0.0f) { cb = edge_weight(dc.y, P.phi_color); nb = dn.y == 0.0f ? 1.0f : edge_weight(fmaxf(dn.y / sw2, 0.0f), P.phi_normal); }
+                w = (v2f){(ca * na) * pa, (cb * nb) * pb};
+            } else {
+                // a channel in which all 64 pixels agree with both their taps (sky: every position is 0; a flat wall: one
+                // normal) has weight exp(-0) = 1 throughout: one compare and a branch the whole wave takes or not
+                const v2f one = {1.0f, 1.0f};
+                v2f pw = one, cw = one, nw = one;
+                if (__ballot((ua | ub) != 0u) != 0ull) pw = edge_weight2(div_uniform2(dp, P.phi_pos, P.rp));
+                if (__ballot((__float_as_uint(dc.x) | __float_as_uint(dc.y)) != 0u) != 0ull) cw = edge_weight2(div_uniform2(dc, P.phi_color, P.rc));
+                if (__ballot((__float_as_uint(dn.x) | __float_as_uint(dn.y)) != 0u) != 0ull)
+                    nw = edge_weight2(div_uniform2(div_uniform2(dn, sw2, P.rs), P.phi_normal, P.rn));
+                w = (cw * nw) * pw;
+            }
+            s01 += ((v2f){oca.x, oca.y} * w.x) * ka; s23 += ((v2f){oca.z, oca.w} * w.x) * ka; total += w.x * ka;
+            s01 += ((v2f){ocb.x, ocb.y} * w.y) * kb; s23 += ((v2f){ocb.z, ocb.w} * w.y) * kb; total += w.y * kb;
+        }
+        if (SHIPPED) {                                         // tap 2, the centre: w = 1, kern = G2
+            s01 += (v2f){sc.x, sc.y} * kGauss2; s23 += (v2f){sc.z, sc.w} * kGauss2;
+            total += kGauss2;
+        }
+        sum[0] = s01.x; sum[1] = s01.y; sum[2] = s23.x; sum[3] = s23.y;
+    } else {
     // pass 0 unrolls into nine LDS reads and 72 multiply-adds; the weighted taps stay a loop (unrolled they need 72
     // VGPRs and 14 KB of code, and measured 7 % slower)
     constexpr int kUnroll = PHI_INF ? 9 : 1;
@@ -1321,6 +1423,7 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
         for (int k = 0; k < 4; k++) sum[k] += (o_c[k] * w) * kern;
         total += w * kern;
     }
+    }
     uchar4 out;
     if (PHI_INF) {
         // sums are 0 or >= 1/255 * 0.77 and total is the fixed sum of the tap weights (3.3 .. 7.7): no operand or
@@ -1351,7 +1454,6 @@ __global__ __launch_bounds__(256) void k_denoise_lds(const DenoiseParams P, int 
 // at a time per wave, so that the guides of the tile + halo are fetched and decoded once for TH rows instead of four (a
 // halo of R = 3 rows above and below makes a 4-row tile read 2.5x its own rows, a 16-row tile 1.4x); the weights are one
 // hardware exponential per tap (see VRT_DENOISE_FAST in vrt.h).
-typedef float v2f __attribute__((ext_vector_type(2)));
 // |a - b|^2 of two float4 in packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: two lanes' worth per instruction);
 // fused and re-associated -- the fast mode states a tolerance, not a rounding
 __device__ __forceinline__ float dist2_pk(const float4& a, const float4& b)
@@ -1456,6 +1558,10 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
         }
         else if (inf) { if (shipped) hipLaunchKernelGGL((k_denoise_lds<true, true>), grid, block, lds, s, p, R);
                    else         hipLaunchKernelGGL((k_denoise_lds<true, false>), grid, block, lds, s, p, R); }
+        else if (p.packed_ok && !(getenv("VRT_DENOISE_PACKED") && getenv("VRT_DENOISE_PACKED")[0] == '0')) {   // (development switch: 0 = the tap-by-tap form)
+            if (shipped) hipLaunchKernelGGL((k_denoise_lds<false, true, false, true>), grid, block, lds, s, p, R);
+            else         hipLaunchKernelGGL((k_denoise_lds<false, false, false, true>), grid, block, lds, s, p, R);
+        }
         else     { if (shipped) hipLaunchKernelGGL((k_denoise_lds<false, true>), grid, block, lds, s, p, R);
                    else         hipLaunchKernelGGL((k_denoise_lds<false, false>), grid, block, lds, s, p, R); }
     } else {

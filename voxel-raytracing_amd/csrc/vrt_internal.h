@@ -194,6 +194,8 @@ struct DenoiseParams {
     float phi_color, phi_normal, phi_pos, step_width;
     int32_t mode;
     float   kc, kn, kp;        // VRT_DENOISE_FAST: log2(e) / phi per channel (kn also / stepWidth^2)
+    float   rc, rn, rp, rs;    // RN(1 / phi) per channel, RN(1 / stepWidth^2): the exact kernel's divisions by pass-uniform values
+    int32_t packed_ok;         // 1: phi and stepWidth^2 are in the range the division by reciprocal + residuals is exact for
     int32_t extend;            // rows beyond each owned strip that this pass must also produce
     ShardMap sh;
 };
