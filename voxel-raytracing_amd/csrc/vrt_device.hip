@@ -976,17 +976,25 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
     const float scale = (fabsf(U[0]) + fabsf(U[1]) + fabsf(U[2])) * (fabsf(V[0]) + fabsf(V[1]) + fabsf(V[2])) * (fabsf(C[0]) + fabsf(C[1]) + fabsf(C[2]));
     bool all = !(fabsf(det) > 1e-3f * scale);
     const float rdet = 1.0f / det;
-    float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
+    // a, b, lambda are linear in p: the corner's numerators once, the other seven corners by additions (a / lambda needs no
+    // determinant); the depth test once per cell, on the smallest lambda against the farthest corner's reach
+    const float p0[3] = {lo[0] - cam[0], lo[1] - cam[1], lo[2] - cam[2]};
+    const float A0 = p0[0] * c0[0] + p0[1] * c0[1] + p0[2] * c0[2], B0 = p0[0] * c1[0] + p0[1] * c1[1] + p0[2] * c1[2];
+    const float L0 = p0[0] * c2[0] + p0[1] * c2[1] + p0[2] * c2[2];
+    const float hw = 0.5f * g.W, hh = 0.5f * g.H;
+    float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f, lam_min = 1e30f;
+#pragma unroll
     for (int k = 0; k < 8; k++) {
-        const float p[3] = {lo[0] + ((k & 1) ? 6.0f : 0.0f) - cam[0], lo[1] + ((k & 2) ? 6.0f : 0.0f) - cam[1], lo[2] + ((k & 4) ? 6.0f : 0.0f) - cam[2]};
-        const float a = (p[0] * c0[0] + p[1] * c0[1] + p[2] * c0[2]) * rdet, b = (p[0] * c1[0] + p[1] * c1[1] + p[2] * c1[2]) * rdet;
-        const float lam = (p[0] * c2[0] + p[1] * c2[1] + p[2] * c2[2]) * rdet;
-        const float reach = fabsf(p[0]) + fabsf(p[1]) + fabsf(p[2]);
-        if (!(lam > 0.05f * reach)) all = true;               // behind the camera plane, or at a grazing angle to it
-        const float rl = __builtin_amdgcn_rcpf(lam);          // (1 ulp: the rectangle has two pixels of margin)
-        const float fx = (a * rl + 1.0f) * 0.5f * g.W, fy = (b * rl + 1.0f) * 0.5f * g.H;
+        const float ex = (k & 1) ? 6.0f : 0.0f, ey = (k & 2) ? 6.0f : 0.0f, ez = (k & 4) ? 6.0f : 0.0f;
+        const float An = A0 + (ex * c0[0] + ey * c0[1] + ez * c0[2]), Bn = B0 + (ex * c1[0] + ey * c1[1] + ez * c1[2]);
+        const float Ln = L0 + (ex * c2[0] + ey * c2[1] + ez * c2[2]);
+        lam_min = fminf(lam_min, Ln * rdet);
+        const float rl = __builtin_amdgcn_rcpf(Ln);          // (1 ulp: the rectangle has two pixels of margin)
+        const float fx = An * rl * hw + hw, fy = Bn * rl * hh + hh;
         x0 = fminf(x0, fx); x1 = fmaxf(x1, fx); y0 = fminf(y0, fy); y1 = fmaxf(y1, fy);
     }
+    // behind the camera plane, or at a grazing angle to it (where fp32 no longer places the corner to a fraction of a pixel)
+    if (!(lam_min > 0.01f * (fabsf(p0[0] + 3.0f) + fabsf(p0[1] + 3.0f) + fabsf(p0[2] + 3.0f) + 9.0f))) all = true;
     if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) all = true;
     const float m = 2.0f;
     int tx0 = (int)floorf(fmaxf(x0 - m, 0.0f) * 0.125f), tx1 = (int)floorf(fminf(x1 + m, g.W - 1.0f) * 0.125f);
@@ -1007,6 +1015,7 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
         const int tyl = local / k;                             // the workgroup tile's local row, and the block's row within the tile
         if (tyl >= T) continue;
         const uint32_t row = (uint32_t)((T - 1 - tyl) * k + (local - tyl * k));
+        // (plain stores; looking first whether the block has its tag already -- most are covered by many cells -- measured slower)
         for (int tx = tx0; tx <= tx1; tx++) tags[row * P.tags_x + (uint32_t)tx] = P.tile_gen;
     }
 }
