@@ -132,3 +132,37 @@ def test_tags_in_batches_and_sharded_launches(vrt, engine, nranks, strip_rows):
             single = _render(vrt, engine, sc, st, pushes[k], False, ["color8"])["color8"]
             assert (got[True][k] == single).all(), (n, k)
     sc.destroy()
+
+
+def test_open_bricks_and_brick_tags_change_nothing(vrt, engine):
+    """Brick scenes: bit 7 of a coarse byte (no occupied brick left in the octant) ends a ray; the tile tags come from the
+    occupied bricks.  Against the dense scene without open cells or tags, and the counters show work going away."""
+    vol = vrt.synthetic.treehouse(64, seed=6)
+    pal = metallic_palette(vrt)
+    sky, noise = vrt.synthetic.sky_gradient(32, 16), vrt.synthetic.blue_noise_standin(32)
+    grid, pool = vrt.synthetic.bricks_from_dense(vol)
+    with _env(VRT_OPEN_CELLS="0"):
+        closed = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
+        bclosed = vrt.VoxelScene.from_bricks(engine, grid, pool, pal, sky=sky, noise=noise)
+    bsc = vrt.VoxelScene.from_bricks(engine, grid, pool, pal, sky=sky, noise=noise)
+    for ci, (p, yaw, pitch) in enumerate(CAMERAS):
+        res = [(96, 64), (131, 77)][ci % 2]
+        st = vrt.VoxelRenderSettings.primary_only(res)
+        if ci % 2:
+            st.occlusionSettings.numSamples = 2; st.traceSettings.shadows = True; st.traceSettings.maxReflections = 2
+        push = camera_push(vrt, (64, 64, 64), res, pos=(p[0] * 64, p[1] * 64, p[2] * 64), yaw=yaw, pitch=pitch, frame=ci)
+        ref = _render(vrt, engine, closed, st, push, False)
+        for name, scene, tags in (("bricks", bclosed, False), ("open bricks", bsc, False), ("open bricks + tags", bsc, True)):
+            bad = compare_planes(_render(vrt, engine, scene, st, push, tags), ref, PRODUCT)
+            assert not bad, (name, ci, bad[:2])
+    st = vrt.VoxelRenderSettings.primary_only((160, 96))
+    push = camera_push(vrt, (64, 64, 64), (160, 96))
+    planes = ["hit_id", "steps_primary", "steps_total", "rays_total"]
+    a, b, c = (_render(vrt, engine, s, st, push, t, planes, flags=1) for s, t in ((bclosed, False), (bsc, False), (bsc, True)))
+    sa, sb, sc_ = (int(x["steps_primary"].astype(np.int64).sum()) for x in (a, b, c))
+    assert sb < sa and sc_ < sb, (sa, sb, sc_)
+    d = _render(vrt, engine, bsc, st, push, True, planes)
+    e = _render(vrt, engine, closed, st, push, False, planes)
+    assert (d["steps_primary"] == e["steps_primary"]).all() and (d["steps_total"] == e["steps_total"]).all()
+    for s in (closed, bclosed, bsc):
+        s.destroy()

@@ -472,6 +472,27 @@ int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32
     SCHK(launch_brick_grid(grid_dev, (int)nbx, (int)nby, (int)nbz, s->bgrid, occ, c->stream));
     // brick-level clearance: the dense scene's transform over the occupancy of the bricks, capped at 16 bricks
     SCHK(launch_build_df(occ, (int)nbx, (int)nby, (int)nbz, s->bcoarse, cstride, tmp0, tmp1, c->stream, 16));
+    // open bricks (bit 7): no occupied brick left between here and the volume's corner in the octant's direction
+    {
+        const char* e = getenv("VRT_OPEN_CELLS");                          // development switch: 0 = no open bricks
+        s->open_cells = !(e && e[0] == '0');
+        if (s->open_cells) SCHK(launch_open_cells(occ, (int)nbx, (int)nby, (int)nbz, s->bcoarse, cstride, tmp0, tmp1, c->stream, 0x80));
+        d.brick_open = s->open_cells ? 1u : 0u;
+    }
+    // the occupied bricks as a list of 8^3 cells, for the tile tags of a launch
+    if (n_bricks <= (4u << 20)) {
+        std::vector<uint32_t> cells(n_bricks);
+        for (uint32_t i = 0; i < n_bricks; i++) {
+            const uint32_t pc = coord[i];
+            cells[i] = (uint32_t)(pc % pbx - 1) | ((uint32_t)((pc / pbx) % pby - 1) << 10) | ((uint32_t)(pc / (pbx * pby) - 1) << 20);
+        }
+        if (n_bricks) {
+            SCHK(hipMalloc((void**)&s->cells, (size_t)n_bricks * 4));
+            SCHK(hipMemcpy(s->cells, cells.data(), (size_t)n_bricks * 4, hipMemcpyHostToDevice));
+            s->bytes += (uint64_t)n_bricks * 4;
+        }
+        s->n_cells = n_bricks; s->cells_ok = true;
+    }
     SCHK(launch_brick_fine(s->bgrid, (int)pbx, (int)pby, coord_dev, n_bricks, s->bpool, s->bfine, c->stream));
     SCHK(hipStreamSynchronize(c->stream));
 #undef SCHK
@@ -773,6 +794,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     bool counts = false;
     if (!(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)))
         for (int f = 0; f < n && !counts; f++) counts = frames[f].steps_primary != nullptr || frames[f].steps_total != nullptr;
+    if (s->bricks && counts) p.sc.vol.brick_open = 0u;
     if (!s->bricks && s->open_cells) {
         if (counts) {
             const uint8_t* fields = nullptr;
@@ -894,7 +916,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     // tile tags: dense scenes, frames with a box rectangle, launches that do not report the reference's iteration counts
     {
         const char* e = getenv("VRT_TILE_TAGS");                          // development switch: 0 = off
-        bool want = !(e && e[0] == '0') && !s->bricks && s->cells_ok && !counts && W <= 8128 && H <= 8128;
+        bool want = !(e && e[0] == '0') && s->cells_ok && !counts && W <= 8128 && H <= 8128;
         bool any = false;
         for (int f = 0; f < n && want && !any; f++) any = !(slots[f].box[0] == 0 && slots[f].box[1] == 255 && slots[f].box[2] == 0 && slots[f].box[3] == 255);
         const bool tags = want && any;
@@ -918,7 +940,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
             }
             p.tile_tags = c->tile_tags; p.tile_gen = c->tile_gen;
             if (tags) {
-                p.cells = s->cells; p.n_cells = s->n_cells;
+                p.cells = s->cells; p.n_cells = s->n_cells; p.cell_size = s->bricks ? 8u : 4u;
                 HIPCHK(launch_tile_tags(p, c->stream));
             } else {
                 // every frame's one word = tile_gen

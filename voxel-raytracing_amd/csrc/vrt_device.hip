@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_open_scan(const uint8_t* __restrict__ v
 }
 
 // scan along x, one wave per line, and the result: 0 into the octant's zero-bordered field where the cell is open
-__global__ __launch_bounds__(256) void k_open_x(const uint8_t* __restrict__ src, uint8_t* __restrict__ field, int W, int H, int D, int dir)
+__global__ __launch_bounds__(256) void k_open_x(const uint8_t* __restrict__ src, uint8_t* __restrict__ field, int W, int H, int D, int dir, int mark)
 {
     const int lane = (int)(threadIdx.x & 63u);
     const size_t line = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -179,12 +179,12 @@ __global__ __launch_bounds__(256) void k_open_x(const uint8_t* __restrict__ src,
         const bool f = x < W ? row[x] != 0 : true;
         const uint64_t blocked = ~__ballot(f);
         const bool open = carry && f && (dir > 0 ? (blocked >> lane) == 0ull : (blocked << (63 - lane)) == 0ull);
-        if (x < W && open) out[x] = 0;
+        if (x < W && open) out[x] = mark ? (uint8_t)(out[x] | (uint8_t)mark) : (uint8_t)0;   // bricks: bit 7; voxels: the code 0
         carry = carry && blocked == 0ull;
     }
 }
 
-hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s)
+hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int mark)
 {
     const unsigned bx = (unsigned)((W + 255) / 256);
     const size_t lines = (size_t)H * (size_t)D;
@@ -192,7 +192,7 @@ hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* d
         const int sx = (o & 1) ? 1 : -1, sy = (o & 2) ? 1 : -1, sz = (o & 4) ? 1 : -1;
         hipLaunchKernelGGL(k_open_scan, dim3(bx, (unsigned)D), dim3(256), 0, s, vox, (const uint8_t*)nullptr, tmp0, W, H, D, 1, sy);
         hipLaunchKernelGGL(k_open_scan, dim3(bx, (unsigned)H), dim3(256), 0, s, vox, (const uint8_t*)tmp0, tmp1, W, H, D, 2, sz);
-        hipLaunchKernelGGL(k_open_x, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, s, (const uint8_t*)tmp1, df + (size_t)o * stride, W, H, D, sx);
+        hipLaunchKernelGGL(k_open_x, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, s, (const uint8_t*)tmp1, df + (size_t)o * stride, W, H, D, sx, mark);
     }
     return hipGetLastError();
 }
@@ -964,7 +964,9 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
     const uint32_t ci = blockIdx.x * 256u + threadIdx.x;
     if (ci >= P.n_cells) return;
     const uint32_t cell = P.cells[ci];
-    const float lo[3] = {(float)((cell & 1023u) * 4u) - 1.0f, (float)(((cell >> 10) & 1023u) * 4u) - 1.0f, (float)((cell >> 20) * 4u) - 1.0f};
+    const uint32_t cs = P.cell_size;                            // 4 (dense scenes: the cells of the 16^3 summaries' bits) or 8 (bricks)
+    const float ext = (float)cs + 2.0f;
+    const float lo[3] = {(float)((cell & 1023u) * cs) - 1.0f, (float)(((cell >> 10) & 1023u) * cs) - 1.0f, (float)((cell >> 20) * cs) - 1.0f};
     uint32_t* tags = P.tile_tags + (size_t)frame * P.tags_per_frame;
     // ray of screen position (a, b) in [-1, 1]^2: C + a U + b V (frag:312-319); [U V C] (a, b, lambda)^T = p - cam
     const float V[3] = {g.planeV.x, g.planeV.y, g.planeV.z};
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
     float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f, lam_min = 1e30f;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const float ex = (k & 1) ? 6.0f : 0.0f, ey = (k & 2) ? 6.0f : 0.0f, ez = (k & 4) ? 6.0f : 0.0f;
+        const float ex = (k & 1) ? ext : 0.0f, ey = (k & 2) ? ext : 0.0f, ez = (k & 4) ? ext : 0.0f;
         const float An = A0 + (ex * c0[0] + ey * c0[1] + ez * c0[2]), Bn = B0 + (ex * c1[0] + ey * c1[1] + ez * c1[2]);
         const float Ln = L0 + (ex * c2[0] + ey * c2[1] + ez * c2[2]);
         lam_min = fminf(lam_min, Ln * rdet);
@@ -994,7 +996,7 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
         x0 = fminf(x0, fx); x1 = fmaxf(x1, fx); y0 = fminf(y0, fy); y1 = fmaxf(y1, fy);
     }
     // behind the camera plane, or at a grazing angle to it (where fp32 no longer places the corner to a fraction of a pixel)
-    if (!(lam_min > 0.01f * (fabsf(p0[0] + 3.0f) + fabsf(p0[1] + 3.0f) + fabsf(p0[2] + 3.0f) + 9.0f))) all = true;
+    if (!(lam_min > 0.01f * (fabsf(p0[0] + 0.5f * ext) + fabsf(p0[1] + 0.5f * ext) + fabsf(p0[2] + 0.5f * ext) + 1.5f * ext))) all = true;
     if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) all = true;
     const float m = 2.0f;
     int tx0 = (int)floorf(fmaxf(x0 - m, 0.0f) * 0.125f), tx1 = (int)floorf(fminf(x1 + m, g.W - 1.0f) * 0.125f);

@@ -181,8 +181,8 @@ struct GeomParams {
     // tile_gen: the frame's tags say nothing (trace every block).  nullptr: no tags in this launch.
     uint32_t*  tile_tags;
     uint32_t   tile_gen, tags_x, tags_y, tags_per_frame;
-    const uint32_t* cells;     // the scene's occupied 4^3 cells, x | y << 10 | z << 20 (in cells)
-    uint32_t   n_cells;
+    const uint32_t* cells;     // the scene's occupied cells (4^3 voxels; 8^3 = the bricks of a brick scene), x | y << 10 | z << 20
+    uint32_t   n_cells, cell_size;
 };
 
 struct DenoiseParams {
@@ -229,7 +229,7 @@ hipError_t launch_brick_grid(const uint32_t* grid, int nbx, int nby, int nbz, ui
 hipError_t launch_brick_fine(const uint32_t* padded, int pbx, int pby, const uint32_t* coord, uint32_t n_bricks, const uint8_t* pool,
                              uint8_t* fine, hipStream_t s);
 hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s);
-hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s);
+hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int mark = 0);
 hipError_t launch_tile_tags(const GeomParams& p, hipStream_t s);
 hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst, hipStream_t s);
 hipError_t launch_primary(const GeomParams& p, hipStream_t s);

@@ -69,7 +69,9 @@ struct VolumeView {
     const uint8_t*  bpool;      // 512 voxel ids per occupied brick, voxel (x,y,z) of the brick at x + 8y + 64z
     const uint8_t*  bfine;      // per occupied brick 8 octants x 512 voxels: 0 = solid, else min(16, side of the largest empty cube
                                 // of VOXELS cornered here ...), looking through the brick's 26 neighbours
-    int32_t         pbx, pby;   // padded grid dimensions in x and y
+    int32_t         pbx, pby;
+    uint32_t        brick_open;  // 1: bit 7 of a coarse byte (no occupied brick is left in the box between this brick and the volume's
+                                // corner in the octant's direction: a ray here is a miss) ends the march; 0: the bit is ignored   // padded grid dimensions in x and y
     int32_t W, H, D;
     int32_t n1x, n1y, n1z;
     int32_t n2x, n2y, n2z;
@@ -1165,7 +1167,11 @@ VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_
 {
     const int bx = (mx >> 3) + 1, by = (my >> 3) + 1, bz = (mz >> 3) + 1;             // (-1 >> 3 = -1: the border brick)
     const size_t bi = (size_t)bx + ((size_t)by + (size_t)bz * (size_t)v.pby) * (size_t)v.pbx;
-    const uint32_t c = v.bcoarse[(size_t)oct * (size_t)v.bcoarse_stride + bi];
+    uint32_t c = v.bcoarse[(size_t)oct * (size_t)v.bcoarse_stride + bi];
+    if (c & 0x80u) {                                           // an open brick: the march ends here as a miss (material stays 0)
+        if (v.brick_open) return 0u;
+        c &= 0x7Fu;
+    }
     const uint32_t lx = (uint32_t)mx & 7u, ly = (uint32_t)my & 7u, lz = (uint32_t)mz & 7u;
     if (c != 0u) {                                             // an empty brick with c - 1 empty bricks behind it on every axis
         const uint32_t rx = sx > 0 ? 8u - lx : lx + 1u, ry = sy > 0 ? 8u - ly : ly + 1u, rz = sz > 0 ? 8u - lz : lz + 1u;
