@@ -106,6 +106,11 @@ typedef struct vrt_frame {
     uint8_t*  hit_id;        /* primary-ray material id, 0 = miss           */
     int16_t*  hit_voxel;     /* 3 / px: grid cell of the hit                */
     uint8_t*  hit_mask;      /* bit0..2 = final DDA mask x,y,z              */
+    /* The two count planes report the iterations of the REFERENCE's loop (every ray walks to a hit, the wall or the end of its
+     * budget).  The product march takes fewer -- rays end where nothing solid is left in their octant, blocks of pixels no
+     * occupied cell projects onto are not traced -- so a launch with a count plane marches a second set of clearance fields
+     * without those shortcuts (built on first use, as large as the first) and uses no tile tags: diagnostics, not for
+     * production launches.  Every other plane is the same either way. */
     uint32_t* steps_primary; /* DDA iterations that sampled a voxel (frag:157), primary ray  */
     uint32_t* steps_total;   /* ... all rays of the pixel                   */
     uint32_t* rays_total;    /* rays traced for the pixel                   */

@@ -48,14 +48,19 @@ except Exception:
     pass
 # K1 of the headline: the DF kernel through the hand-written loop (template argument 7), launches of the whole batch only
 k1 = counters(["k1_fetch", "k1_write", "k1_sq", "k1_misc"], lambda n: "k_primary<7" in n and ", 1, true" in n)
-out = {"kernel": "k_primary<7 (DF, hand-written look-up loop), false, 1 (primary only), true (slot table)>", "frames_per_launch": fpl,
-       "csrc_sha16": csrc_sha16(), "counters": k1, "hbm_bytes_per_launch": hbm(k1)}
+tg = counters(["k1_fetch", "k1_write", "k1_sq", "k1_misc"], lambda n: "k_tile_tags<true>" in n)
+hb = hbm(k1)
+if hb and hbm(tg):                       # one k_tile_tags launch runs ahead of every K1 launch: its traffic belongs to the step
+    for k, v in hbm(tg).items():
+        hb[k] += v
+out = {"kernel": "k_primary<7 (DF, hand-written look-up loop), false, 1 (primary only), true (slot table)> + k_tile_tags<true> ahead of it",
+       "frames_per_launch": fpl, "csrc_sha16": csrc_sha16(), "counters": k1, "counters_k_tile_tags": tg, "hbm_bytes_per_launch": hb}
 json.dump(out, open("profiles/r02_k_primary_pmc.json", "w"), indent=1)
 print("K1:", {k: round(v["mean_per_launch"] / fpl / 1e6, 3) for k, v in k1.items()}, "M per frame;", out["hbm_bytes_per_launch"])
 sets = {
     "r02_megakernel_pmc.json": ("k_primary<7, false, 2 (megakernel)>: config 3 (shadow ray; launches 1-20) and the reference defaults (AO 4, shadow, <= 5 bounces; launches 21-30), 1080p, one frame per launch",
                                 lambda n: "k_primary<7" in n and ", 2, false" in n),
-    "r02_k_denoise_pmc.json": ("k_denoise_lds<false, false, false> (exact weighted pass), 1080p", lambda n: "k_denoise_lds<false, false, false>" in n or "k_denoise_lds<false, false>" in n),
+    "r02_k_denoise_pmc.json": ("k_denoise_lds<false, false, false, true> (exact weighted pass, two taps at a time in packed fp32), 1080p", lambda n: "k_denoise_lds<false, false, false, true>" in n),
     "r02_k_denoise_fast_pmc.json": ("k_denoise_fast<false, 8> (VRT_DENOISE_FAST weighted pass), 1080p", lambda n: "k_denoise_fast" in n),
     "r02_k_denoise_pass0_pmc.json": ("k_denoise_lds<true, false> (pass 0: plain blur), 1080p", lambda n: "k_denoise_lds<true" in n),
     "r02_brick_pmc.json": ("k_primary<6 (BRICK), false, 2 (megakernel)>: BASELINE configs[4], 2048^3 brick scene, 3840x2160, max_steps 6144, 4 bounces, AO 4, one frame per launch",
