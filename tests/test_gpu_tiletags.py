@@ -166,3 +166,35 @@ def test_open_bricks_and_brick_tags_change_nothing(vrt, engine):
     assert (d["steps_primary"] == e["steps_primary"]).all() and (d["steps_total"] == e["steps_total"]).all()
     for s in (closed, bclosed, bsc):
         s.destroy()
+
+
+def test_tags_with_arbitrary_camera_bases(vrt, oracle, engine):
+    """The push block is the caller's: scaled, skewed and mirrored camera bases, a direction that is not unit length, large
+    jitter.  Tags on and off must agree (and agree with the oracle)."""
+    vol = vrt.synthetic.floating_cubes(40, seed=21, count=30)
+    pal = metallic_palette(vrt)
+    sc = vrt.VoxelScene.from_dense(engine, vol, pal, sky=vrt.synthetic.sky_gradient(16, 8))
+    osn = oracle.OracleScene(vol, pal, sky=vrt.synthetic.sky_gradient(16, 8))
+    res = (112, 80)
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    rng = np.random.default_rng(5)
+    for case in range(24):
+        push = camera_push(vrt, (40, 40, 40), res, pos=(20.0 + rng.uniform(-30, 30), 20.0 + rng.uniform(-30, 30), -40.0 - rng.uniform(0, 60)),
+                           yaw=90.0 + rng.uniform(-25, 25), pitch=rng.uniform(-20, 20), jitter=(rng.uniform(-3, 3), rng.uniform(-3, 3)))
+        right = np.array(list(push.cam_right)[:3], np.float32); up = np.array(list(push.cam_up)[:3], np.float32); d = np.array(list(push.cam_dir)[:3], np.float32)
+        kind = case % 6
+        if kind == 0:   right *= 2.5                               # a wide, anamorphic view
+        elif kind == 1: up = up * 0.3 + right * 0.4                # skewed
+        elif kind == 2: right = -right                             # mirrored
+        elif kind == 3: d *= 7.0                                   # direction not normalised (the shader normalises it)
+        elif kind == 4: right *= 0.2; up *= 0.2                    # a long lens
+        else:           up = -up * 1.7
+        push.cam_right[:3] = [float(x) for x in right]; push.cam_up[:3] = [float(x) for x in up]; push.cam_dir[:3] = [float(x) for x in d]
+        a = _render(vrt, engine, sc, st, push, True)
+        b = _render(vrt, engine, sc, st, push, False)
+        bad = compare_planes(a, b, PRODUCT)
+        assert not bad, (case, kind, bad[:2])
+        if case % 3 == 0:
+            exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=PRODUCT, nthreads=8)
+            assert not compare_planes(a, exp, PRODUCT), ("oracle", case)
+    sc.destroy()
