@@ -167,7 +167,8 @@ def single_frame_launch(vrt, engine, renderer, pushes, W, H, S_frames, reps=3):
             "sample": f"{len(pushes)} poses of the step, one vrt_render_geometry call each, device idle between launches"}
 
 
-def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounces, iters, reps=9, max_steps=512, kernel="k_primary<DF, megakernel>"):
+def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounces, iters, reps=9, max_steps=512, kernel="k_primary<DF, megakernel>",
+                 batch_pushes=None):
     """One frame of a secondary-ray configuration: kernel times from the library's HIP events (median of `reps` isolated
     frames), ray / step counts from a second render with the count planes attached."""
     st = vrt.VoxelRenderSettings(targetResolution=(W, H))
@@ -201,6 +202,22 @@ def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounc
            "resolution": [W, H], "max_steps": max_steps, "geometry_kernel": kernel, "geometry_ms": round(g_ms, 5),
            "rays_total": rays, "dda_steps_total": S, "Mrays_total_per_s": round(rays / (g_ms * 1e-3) / 1e6, 1),
            "geometry_algorithmic_bytes": b_geo, "geometry_frac": round(b_geo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    if batch_pushes:
+        # the same settings with several frames per launch (consecutive poses): a hit wave's chain of secondary traces then has
+        # other frames' waves to hide behind, as the headline's primary rays have
+        nb = len(batch_pushes)
+        launch = vrt.GeometryStage(engine, st, scene).prepare_batch(nb)
+        for _ in range(3):
+            launch(batch_pushes)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            launch(batch_pushes)
+        e1.record(); torch.cuda.synchronize()
+        out["geometry_ms_per_frame_batched"] = round(e0.elapsed_time(e1) / 10 / nb, 5)
+        out["batched_frames_per_launch"] = nb
+        del launch
     if iters > 0:
         d_ms = median(td)
         b_den = W * H * (K3_BYTES_PASS0 + (iters - 1) * K3_BYTES_PASS)
@@ -392,7 +409,7 @@ def main():
         extra = None
         if world == 1 and not args.no_extra_configs:
             roofline["single_frame_launch"] = single_frame_launch(vrt, engine, renderer, pushes[:frames_per_launch], W, H, S_frames)
-            extra = [extra_config(vrt, torch, engine, scene, pushes[0], W, H, *c) for c in (
+            extra = [extra_config(vrt, torch, engine, scene, pushes[0], W, H, *c, batch_pushes=pushes[:16]) for c in (
                 ("configs[2]: primary + shadow ray, 1 denoiser pass", 0, True, 0, 1),
                 ("configs[2]: primary + shadow ray, 2 denoiser passes", 0, True, 0, 2),
                 ("reference defaults: AO 4 x 64 steps, shadow ray, <= 5 bounces, 2 denoiser passes", 4, True, 5, 2))]

@@ -11,7 +11,7 @@ pos0, yaw, pitch = vrt.synthetic.default_camera_for(256, 256, 256)
 eng.set_timing(False)
 def pushes_for(n):
     return [vrt.make_push(vrt.CameraController(position=(pos0[0] + 1.5 * f, pos0[1] + 0.5 * f, pos0[2] + 2.0 * f), yaw=yaw, pitch=pitch), (256, 256, 256), res) for f in range(n)]
-def run(st, n, reps=120):
+def run(st, n, reps=40):
     stage = vrt.GeometryStage(eng, st, sc)
     pushes = pushes_for(n)
     launch = stage.prepare_batch(n) if n > 1 else None
@@ -30,4 +30,4 @@ prim = vrt.VoxelRenderSettings.primary_only(res)
 full = vrt.VoxelRenderSettings(targetResolution=res); full.fsrSetttings.enable = False
 cfg3 = vrt.VoxelRenderSettings.primary_only(res); cfg3.traceSettings.shadows = True
 for name, st in (("primary", prim), ("config3", cfg3), ("defaults", full)):
-    print(name, " | ".join(f"{n}/launch {run(st, n):.1f} us/frame" for n in (1, 2, 4, 8)), flush=True)
+    print(name, " | ".join(f"{n}/launch {run(st, n):.1f} us/frame" for n in (1, 8, 32)), flush=True)

@@ -72,6 +72,7 @@ struct vrt_scene {
     // the clearance fields once more without open cells (launch_open_cells): the march the count planes are rendered with,
     // built when a launch first asks for them
     uint8_t* df_counts = nullptr;
+    bool metallic_voxels = true;       // some voxel of the scene has a material with metallic > 0 (only then can a ray bounce, frag:283)
     uint32_t* cells = nullptr;         // occupied 4^3 cells (k_tile_tags), x | y << 10 | z << 20
     uint32_t n_cells = 0;
     bool cells_ok = false;
@@ -274,6 +275,17 @@ int vrt_scene_set_blue_noise(vrt_ctx* c, vrt_scene* s, const uint8_t* rgba8, uin
 
 } // extern "C"
 
+// does any of the n voxel ids have a metallic material?  (decides whether the megakernel needs its bounce stack)
+static bool any_metallic(const uint8_t* ids, size_t n, const vrt_material palette[256])
+{
+    bool metal[256], any = false;
+    for (int i = 0; i < 256; i++) { metal[i] = palette[i].metallic > 0.0f; any = any || (i != 0 && metal[i]); }
+    if (!any) return false;
+    for (size_t i = 0; i < n; i++)
+        if (ids[i] != 0 && metal[ids[i]]) return true;
+    return false;
+}
+
 // The clearance fields of a dense scene into dst (df_bytes: eight fields, or nine and the 0xFF byte in trace_df_fast's layout),
 // from the voxels already on the device; open: with the open cells coded 0 (launch_open_cells).  Returns when they are built.
 static hipError_t build_fields(vrt_ctx* c, const vrt_scene* s, uint8_t* dst, bool open)
@@ -353,6 +365,7 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
         }
     }
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
+    s->metallic_voxels = any_metallic(voxels, nvox, palette);
     SCHK(hipMalloc((void**)&s->vox, nvox));
     SCHK(hipMalloc((void**)&s->occ1, n1 * 8));
     SCHK(hipMalloc((void**)&s->occ2, n2pad * 8));
@@ -450,6 +463,7 @@ int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32
     uint8_t *occ = nullptr, *tmp0 = nullptr, *tmp1 = nullptr;
     int rc = VRT_OK;
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(VRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); goto bad; } } while (0)
+    s->metallic_voxels = any_metallic(pool, pool_bytes, palette);
     SCHK(hipMalloc((void**)&s->bgrid, npad * 4));
     SCHK(hipMalloc((void**)&s->bcoarse, 8 * cstride));
     SCHK(hipMalloc((void**)&s->bpool, pool_bytes ? pool_bytes : 1));
@@ -867,7 +881,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     if (p.xcd_turn != 2) p.tiles_y_rcp = p.tiles_y_local ? (uint32_t)(0x100000000ull / (uint64_t)p.tiles_y_local) : 0u;
     p.tps_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tps);
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
-    p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && st->max_bounces == 0) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
+    p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && (st->max_bounces == 0 || !s->metallic_voxels)) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
+    p.no_bounce = (st->max_bounces == 0 || !s->metallic_voxels) && !(getenv("VRT_NO_BOUNCE_KERNEL") && getenv("VRT_NO_BOUNCE_KERNEL")[0] == '0') ? 1 : 0;
     // default traversal and budgets the recovery of positions from sideDist is exact for: the hand-written look-up loop
     // (vrt_traverse.h trace_df_fast) for every ray of the frame
     {

@@ -566,13 +566,16 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
 }
 
 // colorMainRay, voxel_volume.frag:267-307
-template <int TRAV, class Occ>
+// BOUNCE = false: the host has established that no ray of the frame can bounce (max_bounces == 0, or no voxel of the scene has
+// a metallic material): the loop and its stack of hits -- 352 bytes of scratch per lane, which every wave of the kernel is
+// given whether it bounces or not -- are compiled out
+template <int TRAV, class Occ, bool BOUNCE = true>
 __device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit)
 {
     const DevScene& s = P.sc;
     const vrt_settings& st = P.st;
     f3 reflection = mk3(0.0f, 0.0f, 0.0f);
-    if (s.palette[hit.material].metallic > 0.0f && st.max_bounces > 0) {
+    if (BOUNCE && s.palette[hit.material].metallic > 0.0f && st.max_bounces > 0) {
         RayHit bounces[VRT_MAX_BOUNCES];
         RayHit last = hit;
         int last_idx = -1;
@@ -852,13 +855,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         f.rays_total[i] = (uint32_t)wall_clock64();
     }
 
-    if (MODE != 0) {
+    if (MODE != 0) {                                           // 1: primary only; 2: megakernel; 4: megakernel, nothing can bounce
         f3 col;
         if (hit) {
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame); c.have_noise = false;
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
-                col = color_main_ray<TRAV>(P, occ, c, h);
+                col = color_main_ray<TRAV, OccT<kLds>, MODE != 4>(P, occ, c, h);
                 if (f.steps_total && !(P.st.flags & 3u)) f.steps_total[i] = r.fetches + c.fetches;
                 if (f.rays_total && !(P.st.flags & 3u)) f.rays_total[i] = 1u + c.rays;
             }
@@ -1041,11 +1044,13 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     if (p.table) {               // the split form renders one frame per launch and never gets here
         if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, true>), grid, block, lds, s, p);
-        else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, true>), grid, block, lds, s, p);
+        else if (p.fused_shade == 2) { if (p.no_bounce) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 4, true>), grid, block, lds, s, p);
+                                       else             hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, true>), grid, block, lds, s, p); }
         else return hipErrorInvalidValue;
     }
     else if (p.fused_shade == 1) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, false>), grid, block, lds, s, p);
-    else if (p.fused_shade == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, false>), grid, block, lds, s, p);
+    else if (p.fused_shade == 2) { if (p.no_bounce) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 4, false>), grid, block, lds, s, p);
+                                   else             hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, false>), grid, block, lds, s, p); }
     else                         hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 0, false>), grid, block, lds, s, p);
     return hipGetLastError();
 }

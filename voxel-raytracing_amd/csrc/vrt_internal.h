@@ -173,6 +173,8 @@ struct GeomParams {
     uint32_t*  hit_count;      // K1 -> K2: number of hit pixels (zeroed before K1)
     uint32_t*  hit_list;       // K1 -> K2: their pixel indices, in arrival order
     int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled); 2: megakernel; 0: split
+    int32_t    no_bounce;      // 1: no ray of the launch can bounce (max_bounces == 0 or no metallic voxel in the scene): the megakernel
+                               //    without the bounce loop and its scratch stack
     int32_t    fast_loop;      // 1: AUTO / DF run the hand-written look-up loop (trace_df_fast; the host checked its preconditions)
     int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
     uint32_t   occ2_bytes, occ3_bytes;   // both multiples of 16
