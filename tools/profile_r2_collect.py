@@ -58,8 +58,8 @@ out = {"kernel": "k_primary<7 (DF, hand-written look-up loop), false, 1 (primary
 json.dump(out, open("profiles/r02_k_primary_pmc.json", "w"), indent=1)
 print("K1:", {k: round(v["mean_per_launch"] / fpl / 1e6, 3) for k, v in k1.items()}, "M per frame;", out["hbm_bytes_per_launch"])
 sets = {
-    "r02_megakernel_pmc.json": ("k_primary<7, false, 2 (megakernel)>: config 3 (shadow ray; launches 1-20) and the reference defaults (AO 4, shadow, <= 5 bounces; launches 21-30), 1080p, one frame per launch",
-                                lambda n: "k_primary<7" in n and ", 2, false" in n),
+    "r02_megakernel_pmc.json": ("k_primary<7, false, 4 (megakernel; the scene has no metallic voxel, so the form without the bounce loop)>: config 3 (shadow ray; launches 1-20) and the reference defaults (AO 4, shadow, <= 5 bounces; launches 21-30), 1080p, one frame per launch",
+                                lambda n: "k_primary<7" in n and (", 2, false" in n or ", 4, false" in n)),
     "r02_k_denoise_pmc.json": ("k_denoise_lds<false, false, false, true> (exact weighted pass, two taps at a time in packed fp32), 1080p", lambda n: "k_denoise_lds<false, false, false, true>" in n),
     "r02_k_denoise_fast_pmc.json": ("k_denoise_fast<false, 8> (VRT_DENOISE_FAST weighted pass), 1080p", lambda n: "k_denoise_fast" in n),
     "r02_k_denoise_pass0_pmc.json": ("k_denoise_lds<true, false> (pass 0: plain blur), 1080p", lambda n: "k_denoise_lds<true" in n),
