@@ -78,6 +78,8 @@ struct vrt_scene {
     bool cells_ok = false;
     bool open_cells = false;
     size_t df_bytes = 0;
+    size_t df_guard = 0;               // bytes of room in front of field 0 and behind the last byte of each set of fields: trace_df_fast counts
+                                       // its offsets from (W+2)(H+2) bytes in front of field 0, and its prefetches reach one slice past the border
     std::mutex lazy;
     vrt_material* palette = nullptr;
     float* sky = nullptr;
@@ -226,8 +228,8 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->occ1) hipFree(s->occ1);
     if (s->occ2) hipFree(s->occ2);
     if (s->occ3) hipFree(s->occ3);
-    if (s->df) hipFree(s->df);
-    if (s->df_counts) hipFree(s->df_counts);
+    if (s->df) hipFree(s->df - s->df_guard);
+    if (s->df_counts) hipFree(s->df_counts - s->df_guard);
     if (s->cells) hipFree(s->cells);
     if (s->palette) hipFree(s->palette);
     if (s->sky) hipFree(s->sky);
@@ -321,10 +323,11 @@ static int fields_for_counts(vrt_ctx* c, const vrt_scene* cs, const uint8_t** ou
             return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: the count planes (steps_primary, steps_total) need a second set of clearance fields (" +
                         std::to_string((uint64_t)s->df_bytes) + " bytes), which does not fit the device memory that is free");
         uint8_t* p = nullptr;
-        HIPCHK(hipMalloc((void**)&p, s->df_bytes));
-        hipError_t e = build_fields(c, s, p, false);
+        HIPCHK(hipMalloc((void**)&p, s->df_bytes + 2 * s->df_guard));
+        hipError_t e = hipMemsetAsync(p, 0, s->df_bytes + 2 * s->df_guard, c->stream);
+        if (e == hipSuccess) e = build_fields(c, s, p + s->df_guard, false);
         if (e != hipSuccess) { hipFree(p); return fail(VRT_ERR_HIP, std::string("building the count planes' clearance fields: ") + hipGetErrorString(e)); }
-        s->df_counts = p;
+        s->df_counts = p + s->df_guard;
         s->bytes += s->df_bytes;
     }
     *out = s->df_counts;
@@ -376,7 +379,13 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     {
         const bool fast = 9ull * ndf + 256ull <= 0xFFFFFFFFull && ((uint64_t)W + 2u) * ((uint64_t)H + 2u) < (1ull << 23);
         const size_t bytes = fast ? 9 * ndf + 256 : 8 * ndf;
-        SCHK(hipMalloc((void**)&s->df, bytes));
+        s->df_guard = ((((size_t)W + 2u) * ((size_t)H + 2u)) * 2u + 511u) & ~(size_t)255u;
+        {
+            uint8_t* raw = nullptr;
+            SCHK(hipMalloc((void**)&raw, bytes + 2 * s->df_guard));
+            s->df = raw + s->df_guard;
+            SCHK(hipMemsetAsync(raw, 0, bytes + 2 * s->df_guard, c->stream));
+        }
         s->df_bytes = bytes;
         s->bytes = (uint64_t)nvox + bytes + (n1 + n2pad + n3pad) * 8ull + 256 * sizeof(vrt_material);
         d.df_fast = fast ? 1u : 0u;
@@ -416,6 +425,10 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     }
 #undef SCHK
     d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.df = s->df; d.df_stride = ndf; s->d.palette = s->palette;
+    {
+        const char* e = getenv("VRT_DF_PREFETCH");                         // development switch: 0 = no neighbour-row prefetch in the secondary rays' look-ups
+        d.df_prefetch = (d.df_fast && !(e && e[0] == '0')) ? 1u : 0u;
+    }
     s->occ2_bytes = (uint32_t)(n2pad * 8); s->occ3_bytes = (uint32_t)(n3pad * 8);
     {
         const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};

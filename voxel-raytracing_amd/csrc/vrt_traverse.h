@@ -70,6 +70,7 @@ struct VolumeView {
     const uint8_t*  bfine;      // per occupied brick 8 octants x 512 voxels: 0 = solid, else min(16, side of the largest empty cube
                                 // of VOXELS cornered here ...), looking through the brick's 26 neighbours
     int32_t         pbx, pby;
+    uint32_t        df_prefetch; // 1: the secondary rays' look-ups through trace_df_fast prefetch the neighbouring rows (development switch)
     uint32_t        brick_open;  // 1: bit 7 of a coarse byte (no occupied brick is left in the box between this brick and the volume's
                                 // corner in the octant's direction: a ray here is a miss) ends the march; 0: the bit is ignored   // padded grid dimensions in x and y
     int32_t W, H, D;
@@ -804,7 +805,7 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
                                              float& x, float& y, float& z, float dx, float dy, float dz,
                                              float gx, float gy, float gz, float cx, float cy, float cz,
                                              uint32_t idx0, uint32_t voxoff, uint32_t& lmask, uint32_t& material, uint32_t& fetches,
-                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz, uint32_t anyhit)
+                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz, uint32_t anyhit, uint32_t pf)
 {
     // the same iteration that also moves the index of the lane's voxel: one more vector instruction per axis under the
     // EXEC mask that is there anyway -- cheaper than recovering the position afterwards for runs of up to four iterations
@@ -834,6 +835,21 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_mov_b64 exec, s[68:69]\n\t"                                  \
         "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
         "v_add_f32 %[z], %[z], %[dz]\n\t"
+    // Secondary rays (pf != 0): with every look-up the bytes one step further along y and along z are asked for as well and
+    // thrown away -- a ray creeping along a surface looks at memory after every iteration, each look a 64-lane gather that
+    // comes from beyond the L2, and with a fifth of the pixels hitting there are no other waves to hide that behind; the next
+    // cell of a single-iteration run is one of this cell's three neighbours (the one along x shares its cache line), so the
+    // next look finds its line in the vector L1.  (Up to one row / slice past the fields' one-voxel border: the fields are
+    // allocated with that much room around them and indexed from pwh bytes in front of field 0.)  The look-up's own load is
+    // the oldest of the three: label 10 waits for all but the two youngest.
+#define VRT_F_PREFETCH                                           \
+        "s_cmp_eq_u32 %[pf], 0\n\t"                               \
+        "s_cbranch_scc1 7f\n\t"                                   \
+        "v_add_u32 v54, v53, %[iy]\n\t"                           \
+        "global_load_ubyte v55, v54, %[base]\n\t"                 \
+        "v_add_u32 v54, v53, %[iz]\n\t"                           \
+        "global_load_ubyte v56, v54, %[base]\n\t"                 \
+        "7:\n\t"
     // scalars of the block: s60 = i (iterations done by every live lane), s61 = kw, s62 = left / iterations still to do,
     // s63 = 0xFF, s[66:67] = saved EXEC; vectors: v48..v50 temporaries, v52 = the byte read = the lane's vote,
     // v53 = index of the byte to read next
@@ -855,7 +871,13 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_mov_b64 s[68:69], exec\n\t"
         "v_mov_b32 v53, %[idx0]\n\t"
         "global_load_ubyte v52, v53, %[base]\n\t"
+        VRT_F_PREFETCH
         "10:\n\t"                                                   // ---- look-up: every lane's byte is here ----
+        "s_cmp_eq_u32 %[pf], 0\n\t"
+        "s_cbranch_scc1 8f\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "s_branch 11f\n\t"
+        "8:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "11:\n\t"
         // any-hit rays (AO, shadow): a lane whose clearance covers what is left of its budget will test nothing but empty voxels
@@ -970,6 +992,7 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t"
         "v_add_u32 v53, %[idx0], v48\n\t"
         "global_load_ubyte v52, v53, %[base]\n\t"
+        VRT_F_PREFETCH
         "s_cmp_lt_u32 s60, %[maxs]\n\t"
         "s_cbranch_scc1 10b\n\t"
         // ---- the budget is spent: the lanes that are still live (their start index is not the 0xFF byte's) stop here ----
@@ -1054,6 +1077,7 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "v_add_u32 v53, v53, %[iz]\n\t"
         "s_mov_b64 exec, s[68:69]\n\t"
         "global_load_ubyte v52, v53, %[base]\n\t"
+        VRT_F_PREFETCH
         "s_cmp_lt_u32 s60, %[maxs]\n\t"
         "s_cbranch_scc1 10b\n\t"
         "s_branch 19b\n\t"
@@ -1094,14 +1118,16 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
           [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
           [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), [fet] "+v"(fetches),
           [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz)
-        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [any] "s"(anyhit)
-        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53",
+        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [any] "s"(anyhit), [pf] "s"(pf)
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55", "v56",
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69");
 #undef VRT_F_EITER
 #undef VRT_F_EITER_IDX
+#undef VRT_F_PREFETCH
 }
 
-template <class STATS, bool ANYHIT = false>
+// PF: the look-ups ask for the two neighbouring rows as well (secondary rays: VRT_F_PREFETCH)
+template <class STATS, bool ANYHIT = false, bool PF = false>
 __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -1115,15 +1141,16 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     const bool done0 = oob(v, s.mx, s.my, s.mz);
     const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
     const uint32_t stride = (uint32_t)v.df_stride;
-    const uint32_t octoff = oct * stride, sentinel = 9u * stride;
     const int pw = v.W + 2, pwh = pw * (v.H + 2);
+    // offsets count from pwh bytes in front of field 0 (room for a prefetch one slice before it: vrt_api.hip df_guard)
+    const uint32_t bias = (uint32_t)pwh, octoff = bias + oct * stride, sentinel = bias + 9u * stride;
     const float kInf = u2f(0x7F800000u);
     // a lane that never enters the volume is finished from the start: zero deltas, the 0xFF byte
     float dx = done0 ? 0.0f : s.dx, dy = done0 ? 0.0f : s.dy, dz = done0 ? 0.0f : s.dz;
     float gx = (!done0 && s.dx < kInf) ? dir.x : 0.0f, gy = (!done0 && s.dy < kInf) ? dir.y : 0.0f, gz = (!done0 && s.dz < kInf) ? dir.z : 0.0f;
     float cx = gx != 0.0f ? -(s.sdx * gx) : 0.0f, cy = gy != 0.0f ? -(s.sdy * gy) : 0.0f, cz = gz != 0.0f ? -(s.sdz * gz) : 0.0f;
     const uint32_t idx0 = done0 ? sentinel : octoff + (uint32_t)df_index(v, s.mx, s.my, s.mz);
-    const uint32_t voxoff = 8u * stride - octoff;
+    const uint32_t voxoff = 8u * stride - (octoff - bias);
     uint32_t lmask = s.mask, material = 0u, fetches = 0u;
     const uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
     float x = s.sdx, y = s.sdy, z = s.sdz;
@@ -1131,19 +1158,19 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     const int incx = done0 ? 0 : s.sx, incy = done0 ? 0 : s.sy * pw, incz = done0 ? 0 : s.sz * pwh;
     // the block's scalar operands must BE in scalar registers: values that are uniform but were computed under divergent
     // control flow (secondary rays) may live in vector registers
-    const uint64_t b64 = (uint64_t)v.df;
+    const uint64_t b64 = (uint64_t)v.df - (uint64_t)bias;
     const uint8_t* base = (const uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));      // (the builtin returns int)
     df_fast_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
-                 incx, incy, incz, ANYHIT ? 1u : 0u);
+                 incx, incy, incz, ANYHIT ? 1u : 0u, PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v.df_prefetch) : 0u);
     s.sdx = x; s.sdy = y; s.sdz = z;
     finish(s, material, lmask, fetches + (material != 0u ? 1u : 0u), r);
     (void)stats;
 }
 #else
 // host pass of a .hip file / the host build of the unit tests: parsed, never run (the loop is gfx950 assembly)
-template <class STATS, bool ANYHIT = false>
+template <class STATS, bool ANYHIT = false, bool PF = false>
 VRT_HD void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 #endif
 
@@ -1612,7 +1639,7 @@ VRT_HD void trace_dfj(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, 
 // Dispatcher used by the kernels.
 // ANYHIT: the caller only uses r.material and r.fetches (traceRayHit, frag:198-202): a traversal may then stop stepping a ray
 // that is certain to exhaust its budget in empty space (DF_FAST does)
-template <int TRAV, class OP, bool AHEAD = false, bool ANYHIT = false>
+template <int TRAV, class OP, bool AHEAD = false, bool ANYHIT = false, bool PF = false>
 VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
                       uint32_t maxSteps, RayInt& r)
 {
@@ -1624,7 +1651,7 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
         trace_brick<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
-        trace_df_fast<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
+        trace_df_fast<NoStats, ANYHIT, PF>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF) {
         NoStats ns;
         trace_df<NoStats, AHEAD>(v, start, dir, maxSteps, r, ns);
