@@ -428,6 +428,8 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     {
         const char* e = getenv("VRT_DF_PREFETCH");                         // development switch: 0 = no neighbour-row prefetch in the secondary rays' look-ups
         d.df_prefetch = (d.df_fast && !(e && e[0] == '0')) ? 1u : 0u;
+        const char* o = getenv("VRT_DF_OWN");                              // development switch: 0 = the AO rays through the wave-minimum loop too
+        d.df_own = (d.df_fast && !(o && o[0] == '0')) ? 1u : 0u;
     }
     s->occ2_bytes = (uint32_t)(n2pad * 8); s->occ3_bytes = (uint32_t)(n3pad * 8);
     {

@@ -521,7 +521,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
             f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
             RayInt r;
             // AO rays have a 64-iteration budget: too short for jumps to pay, and budget ties would force re-traces
-            trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV), decltype(occ.o2), false, true, false>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);   // (no prefetch: AO rays point every way, three gathers instead of one measured +18 %)
+            trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV), decltype(occ.o2), false, true, false, true>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);   // (no prefetch: AO rays point every way, three gathers instead of one measured +18 %)
             c.fetches += r.fetches; c.rays++;
             if (r.material != 0) ambient += sample_frac;
         }

@@ -70,6 +70,7 @@ struct VolumeView {
     const uint8_t*  bfine;      // per occupied brick 8 octants x 512 voxels: 0 = solid, else min(16, side of the largest empty cube
                                 // of VOXELS cornered here ...), looking through the brick's 26 neighbours
     int32_t         pbx, pby;
+    uint32_t        df_own;      // 1: AO rays through df_any_loop (development switch)
     uint32_t        df_prefetch; // 1: the secondary rays' look-ups through trace_df_fast prefetch the neighbouring rows (development switch)
     uint32_t        brick_open;  // 1: bit 7 of a coarse byte (no occupied brick is left in the box between this brick and the volume's
                                 // corner in the octant's direction: a ray here is a miss) ends the march; 0: the bit is ignored   // padded grid dimensions in x and y
@@ -1126,8 +1127,121 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
 #undef VRT_F_PREFETCH
 }
 
+// ---- the same march for rays that point every way (AO): every lane spends ITS OWN clearance -------------------------------
+// The lanes of a primary or a shadow wave are neighbours going the same way, and the wave-wide minimum of their clearances
+// costs little.  The AO rays of a wave point every way from a surface: somebody's cube is always tiny, the minimum is 1 or 2, and
+// the wave looks at memory -- a gather of 64 unrelated cache lines -- after every iteration or two.  Here a lane that read
+// clearance c takes c iterations of its own while the others take theirs (an iteration runs under the mask of the lanes that
+// still have some left: one compare and one subtraction more than the 7 instructions of the plain one), and the wave looks
+// again only when everybody has used his up: the number of looks is the number the NEEDIEST lane needs, not the sum over the
+// minima.  Positions from the sideDist travelled, as in the long runs of df_fast_loop.  Any-hit rays only: no mask bits, no
+// per-lane iteration of a hit to remember -- a lane's own iteration count (fetches) is its i.
+// Same fp32 additions per lane, in the same order: bit-identical results.  Runs under the EXEC mask it is entered with.
+#ifndef VRT_OWN_CAP
+#define VRT_OWN_CAP 4
+#endif
+__device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
+                                            float& x, float& y, float& z, float dx, float dy, float dz,
+                                            float gx, float gy, float gz, float cx, float cy, float cz,
+                                            uint32_t idx0, uint32_t voxoff, uint32_t& material, uint32_t& fetches)
+{
+    // vectors of the block: v48..v50 temporaries, v52 the byte read, v53 its index, v54 = i (iterations this lane has taken),
+    // v55 = iterations this lane may still take before it has to look again; scalars: s63 = 0xFF, s[64:65] lanes with some left,
+    // s[66:67] saved EXEC, s[68:69] EXEC on entry
+#define VRT_A_FINISH                                             \
+        "v_mov_b32 %[dx], 0\n\t"                                  \
+        "v_mov_b32 %[dy], 0\n\t"                                  \
+        "v_mov_b32 %[dz], 0\n\t"                                  \
+        "v_mov_b32 %[gx], 0\n\t"                                  \
+        "v_mov_b32 %[gy], 0\n\t"                                  \
+        "v_mov_b32 %[gz], 0\n\t"                                  \
+        "v_mov_b32 %[cx], 0\n\t"                                  \
+        "v_mov_b32 %[cy], 0\n\t"                                  \
+        "v_mov_b32 %[cz], 0\n\t"                                  \
+        "v_mov_b32 %[idx0], %[sent]\n\t"                          \
+        "v_mov_b32 v53, %[sent]\n\t"                              \
+        "v_mov_b32 v52, s63\n\t"
+    asm volatile(
+        ".p2align 6\n\t"
+        "s_movk_i32 s63, 0xff\n\t"
+        "s_mov_b64 s[68:69], exec\n\t"
+        "v_mov_b32 v53, %[idx0]\n\t"
+        "v_mov_b32 v54, 0\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "10:\n\t"                                                   // ---- every lane's byte is here ----
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t"                        // solid, border or open cell: the lane ends here
+        "s_cbranch_vccz 12f\n\t"
+        "s_and_saveexec_b64 s[66:67], vcc\n\t"
+        "v_add_u32 v48, v53, %[voxoff]\n\t"
+        "global_load_ubyte %[mat], v48, %[base]\n\t"              // the voxel id says which
+        "v_mov_b32 %[fet], v54\n\t"
+        VRT_A_FINISH
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "12:\n\t"
+        "v_cmp_ne_u32_e64 s[64:65], s63, v52\n\t"                 // live lanes ...
+        "v_sub_u32 v48, %[maxs], v54\n\t"                         // ... what is left of their budget ...
+        "s_nop 0\n\t"
+        "v_cmp_le_u32_e32 vcc, v48, v52\n\t"                      // ... and whether the clearance covers it: a miss at the budget
+        "s_and_b64 vcc, vcc, s[64:65]\n\t"
+        "s_cbranch_vccz 13f\n\t"
+        "s_and_saveexec_b64 s[66:67], vcc\n\t"
+        "v_mov_b32 %[fet], %[maxs]\n\t"
+        VRT_A_FINISH
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "13:\n\t"
+        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t"                      // who is live now
+        "s_cbranch_vccz 40f\n\t"                                  // nobody: done
+        "v_cndmask_b32_e32 v55, 0, v52, vcc\n\t"                  // iterations the lane may take: its clearance (0 for a finished lane)
+        "v_min_u32 v55, " VRT_STR(VRT_OWN_CAP) ", v55\n\t"          // ... but no more than a few: the others wait for the longest
+        "v_add_u32 v54, v54, v55\n\t"                             // it will take them all before the next look
+        "20:\n\t"                                                   // ---- one iteration for the lanes that have some left ----
+        "v_cmp_lt_u32_e32 vcc, 0, v55\n\t"
+        "s_cbranch_vccz 30f\n\t"
+        "s_mov_b64 s[64:65], vcc\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_subrev_u32 v55, 1, v55\n\t"
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
+        "v_cmpx_eq_u32 v48, %[x]\n\t"
+        "v_add_f32 %[x], %[x], %[dx]\n\t"
+        "s_mov_b64 exec, s[64:65]\n\t"
+        "v_cmpx_eq_u32 v48, %[y]\n\t"
+        "v_add_f32 %[y], %[y], %[dy]\n\t"
+        "s_mov_b64 exec, s[64:65]\n\t"
+        "v_cmpx_eq_u32 v48, %[z]\n\t"
+        "v_add_f32 %[z], %[z], %[dz]\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        "s_branch 20b\n\t"
+        "30:\n\t"                                                   // ---- where is every lane now?  request its next byte ----
+        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"
+        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t"
+        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t"
+        "v_add_f32 v48, v48, %[cx]\n\t"
+        "v_add_f32 v49, v49, %[cy]\n\t"
+        "v_add_f32 v50, v50, %[cz]\n\t"
+        "v_cvt_rpi_i32_f32 v48, v48\n\t"
+        "v_cvt_rpi_i32_f32 v49, v49\n\t"
+        "v_cvt_rpi_i32_f32 v50, v50\n\t"
+        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t"
+        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t"
+        "v_add_u32 v53, %[idx0], v48\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "s_branch 10b\n\t"
+        "40:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
+          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
+          [idx0] "+v"(idx0), [mat] "+v"(material), [fet] "+v"(fetches)
+        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55",
+          "s63", "s64", "s65", "s66", "s67", "s68", "s69");
+#undef VRT_A_FINISH
+}
+
 // PF: the look-ups ask for the two neighbouring rows as well (secondary rays: VRT_F_PREFETCH)
-template <class STATS, bool ANYHIT = false, bool PF = false>
+// OWN: every lane spends its own clearance (df_any_loop; any-hit rays)
+template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false>
 __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -1161,6 +1275,10 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     const uint64_t b64 = (uint64_t)v.df - (uint64_t)bias;
     const uint8_t* base = (const uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));      // (the builtin returns int)
+    if (ANYHIT && OWN && __builtin_amdgcn_readfirstlane((int)v.df_own) != 0) {
+        df_any_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, material, fetches);
+    } else
     df_fast_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
                  incx, incy, incz, ANYHIT ? 1u : 0u, PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v.df_prefetch) : 0u);
@@ -1170,7 +1288,7 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
 }
 #else
 // host pass of a .hip file / the host build of the unit tests: parsed, never run (the loop is gfx950 assembly)
-template <class STATS, bool ANYHIT = false, bool PF = false>
+template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false>
 VRT_HD void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 #endif
 
@@ -1639,7 +1757,7 @@ VRT_HD void trace_dfj(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, 
 // Dispatcher used by the kernels.
 // ANYHIT: the caller only uses r.material and r.fetches (traceRayHit, frag:198-202): a traversal may then stop stepping a ray
 // that is certain to exhaust its budget in empty space (DF_FAST does)
-template <int TRAV, class OP, bool AHEAD = false, bool ANYHIT = false, bool PF = false>
+template <int TRAV, class OP, bool AHEAD = false, bool ANYHIT = false, bool PF = false, bool OWN = false>
 VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
                       uint32_t maxSteps, RayInt& r)
 {
@@ -1651,7 +1769,7 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
         trace_brick<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
-        trace_df_fast<NoStats, ANYHIT, PF>(v, start, dir, maxSteps, r, ns);
+        trace_df_fast<NoStats, ANYHIT, PF, OWN>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF) {
         NoStats ns;
         trace_df<NoStats, AHEAD>(v, start, dir, maxSteps, r, ns);
