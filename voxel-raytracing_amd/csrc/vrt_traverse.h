@@ -1148,6 +1148,22 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
     // vectors of the block: v48..v50 temporaries, v52 the byte read, v53 its index, v54 = i (iterations this lane has taken),
     // v55 = iterations this lane may still take before it has to look again; scalars: s63 = 0xFF, s[64:65] lanes with some left,
     // s[66:67] saved EXEC, s[68:69] EXEC on entry
+#define VRT_A_ITER                                               \
+        "v_cmp_lt_u32_e32 vcc, 0, v55\n\t"                        \
+        "s_cbranch_vccz 30f\n\t"                                  \
+        "s_mov_b64 s[64:65], vcc\n\t"                             \
+        "s_mov_b64 exec, vcc\n\t"                                 \
+        "v_subrev_u32 v55, 1, v55\n\t"                            \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
+        "v_cmpx_eq_u32 v48, %[x]\n\t"                             \
+        "v_add_f32 %[x], %[x], %[dx]\n\t"                         \
+        "s_mov_b64 exec, s[64:65]\n\t"                            \
+        "v_cmpx_eq_u32 v48, %[y]\n\t"                             \
+        "v_add_f32 %[y], %[y], %[dy]\n\t"                         \
+        "s_mov_b64 exec, s[64:65]\n\t"                            \
+        "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
+        "v_add_f32 %[z], %[z], %[dz]\n\t"                         \
+        "s_mov_b64 exec, s[68:69]\n\t"
 #define VRT_A_FINISH                                             \
         "v_mov_b32 %[dx], 0\n\t"                                  \
         "v_mov_b32 %[dy], 0\n\t"                                  \
@@ -1195,22 +1211,8 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
         "v_cndmask_b32_e32 v55, 0, v52, vcc\n\t"                  // iterations the lane may take: its clearance (0 for a finished lane)
         "v_min_u32 v55, " VRT_STR(VRT_OWN_CAP) ", v55\n\t"          // ... but no more than a few: the others wait for the longest
         "v_add_u32 v54, v54, v55\n\t"                             // it will take them all before the next look
-        "20:\n\t"                                                   // ---- one iteration for the lanes that have some left ----
-        "v_cmp_lt_u32_e32 vcc, 0, v55\n\t"
-        "s_cbranch_vccz 30f\n\t"
-        "s_mov_b64 s[64:65], vcc\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_subrev_u32 v55, 1, v55\n\t"
-        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
-        "v_cmpx_eq_u32 v48, %[x]\n\t"
-        "v_add_f32 %[x], %[x], %[dx]\n\t"
-        "s_mov_b64 exec, s[64:65]\n\t"
-        "v_cmpx_eq_u32 v48, %[y]\n\t"
-        "v_add_f32 %[y], %[y], %[dy]\n\t"
-        "s_mov_b64 exec, s[64:65]\n\t"
-        "v_cmpx_eq_u32 v48, %[z]\n\t"
-        "v_add_f32 %[z], %[z], %[dz]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
+        "20:\n\t"                                                   // ---- iterations for the lanes that have some left (four per trip) ----
+        VRT_A_ITER VRT_A_ITER VRT_A_ITER VRT_A_ITER
         "s_branch 20b\n\t"
         "30:\n\t"                                                   // ---- where is every lane now?  request its next byte ----
         "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"
@@ -1237,6 +1239,7 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55",
           "s63", "s64", "s65", "s66", "s67", "s68", "s69");
 #undef VRT_A_FINISH
+#undef VRT_A_ITER
 }
 
 // PF: the look-ups ask for the two neighbouring rows as well (secondary rays: VRT_F_PREFETCH)
