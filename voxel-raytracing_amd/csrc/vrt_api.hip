@@ -507,6 +507,8 @@ int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32
         s->open_cells = !(e && e[0] == '0');
         if (s->open_cells) SCHK(launch_open_cells(occ, (int)nbx, (int)nby, (int)nbz, s->bcoarse, cstride, tmp0, tmp1, c->stream, 0x80));
         d.brick_open = s->open_cells ? 1u : 0u;
+        const char* o = getenv("VRT_DF_OWN");                              // development switch: 0 = the AO rays through the wave-minimum loop too
+        d.df_own = !(o && o[0] == '0') ? 1u : 0u;
     }
     // the occupied bricks as a list of 8^3 cells, for the tile tags of a launch
     if (n_bricks <= (4u << 20)) {

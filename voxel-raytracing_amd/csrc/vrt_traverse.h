@@ -1424,6 +1424,60 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The brick march for rays that point every way (AO): every lane spends its own clearance, up to VRT_OWN_CAP iterations per
+// look (df_any_loop's scheme in the generic loop: an iteration runs under the ballot of the lanes that have some left).
+template <class STATS>
+__device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
+{
+    DdaState s;
+    dda_entry(v, start, dir, s);
+    if (wave_all(oob(v, s.mx, s.my, s.mz))) {
+        s.dx = s.dy = s.dz = 0.0f; s.sdx = s.sdy = s.sdz = 0.0f; s.sx = s.sy = s.sz = 0;
+        finish(s, 0u, s.mask, 0u, r);
+        return;
+    }
+    dda_rest(dir, s);
+    asm volatile("" : "+v"(s.dx), "+v"(s.dy), "+v"(s.dz));
+    uint32_t material = 0u, fetches = 0u, i = 0u;             // i: iterations THIS lane has taken
+    bool done = oob(v, s.mx, s.my, s.mz);
+    const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
+    const float kInf = u2f(0x7F800000u);
+    const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
+    for (;;) {
+        uint32_t own = 0u;
+        if (!done) {
+            if (i >= maxSteps) { done = true; fetches = i; }
+            else {
+                uint32_t m = 0u;
+                const uint32_t clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m);
+                st_lookup(stats);
+                if (clear == 0u) {
+                    if (oob(v, s.mx, s.my, s.mz)) fetches = i;
+                    else { material = m; fetches = i + 1u; }
+                    done = true;
+                } else if (clear >= maxSteps - i) { done = true; fetches = maxSteps; }
+                else own = clear < (uint32_t)VRT_OWN_CAP ? clear : (uint32_t)VRT_OWN_CAP;
+            }
+        }
+        if (__ballot(own != 0u) == 0ull) break;
+        const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)VRT_OWN_CAP; j++) {
+            const uint64_t mk = __ballot(own > j);
+            if (mk == 0ull) break;
+            dda_advance_live(s, mk);
+        }
+        s.mx += steps_signed(s.sdx - ox, gx); s.my += steps_signed(s.sdy - oy, gy); s.mz += steps_signed(s.sdz - oz, gz);
+        i += own;
+    }
+    finish(s, material, s.mask, fetches, r);
+}
+#else
+template <class STATS>
+VRT_HD void trace_brick_own(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
+#endif
+
 // DENSE: one R8 fetch per iteration.  Straight-line body with a single exit (out of budget, out of bounds or
 // solid), the voxel index maintained incrementally in IDX (uint32_t for volumes below 4 GiB).
 template <class IDX>
@@ -1769,7 +1823,8 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
         trace_jump(v, o2, o3, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_BRICK) {
         NoStats ns;
-        trace_brick<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
+        if (ANYHIT && OWN && v.df_own) trace_brick_own(v, start, dir, maxSteps, r, ns);
+        else trace_brick<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
         trace_df_fast<NoStats, ANYHIT, PF, OWN>(v, start, dir, maxSteps, r, ns);
