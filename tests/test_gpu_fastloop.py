@@ -176,3 +176,39 @@ def test_fast_loop_random_sweep(vrt, oracle, engine):
         bad = compare_planes(_render(vrt, engine, sc, st, push, True, PRODUCT), exp, PRODUCT)            # the product march: open cells
         assert not bad, ("open cells", case, kind, vol.shape, res, st.traceSettings.maxRaySteps, pos, yaw, pitch, bad[:2])
         sc.destroy()
+
+
+def test_secondary_ray_loops_agree(vrt, oracle, engine):
+    """AO rays spend their own clearance (df_any_loop), shadow and bounce rays prefetch their neighbours' rows: every plane,
+    the count planes included, equals what the wave-minimum loop without prefetch gives, and the oracle's."""
+    vol = vrt.synthetic.treehouse(64, seed=11)
+    vol[20:24, 30:34, 20:24] = 230                                # something metallic to bounce off
+    pal = metallic_palette(vrt)
+    sky, noise = vrt.synthetic.sky_gradient(32, 16), vrt.synthetic.blue_noise_standin(32)
+    scenes = {}
+    for own, pf in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        old = {k: os.environ.get(k) for k in ("VRT_DF_OWN", "VRT_DF_PREFETCH")}
+        os.environ["VRT_DF_OWN"], os.environ["VRT_DF_PREFETCH"] = own, pf
+        try:
+            scenes[(own, pf)] = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+    osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
+    for ci, (pos, yaw, pitch, ao, ao_steps, max_steps) in enumerate((((32.3, 30.1, -40.0), 90.0, 0.0, 4, 64, 512), ((10.0, 50.0, 10.0), 45.0, -30.0, 3, 16, 200),
+                                                                      ((32.0, 20.0, 32.0), 10.0, 5.0, 5, 1, 37), ((80.0, 70.0, -30.0), 130.0, -25.0, 2, 64, 1000))):
+        res = (120, 88)
+        st = vrt.VoxelRenderSettings(targetResolution=res)
+        st.fsrSetttings.enable = False
+        st.occlusionSettings.numSamples = ao; st.traceSettings.aoSteps = ao_steps; st.traceSettings.maxRaySteps = max_steps
+        st.traceSettings.shadows = True; st.traceSettings.maxReflections = 3
+        push = camera_push(vrt, (64, 64, 64), res, pos=pos, yaw=yaw, pitch=pitch, frame=ci)
+        exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=PLANES, nthreads=8)
+        for key, sc in scenes.items():
+            bad = compare_planes(_render(vrt, engine, sc, st, push, True), exp, PLANES)           # through the fields without open cells
+            assert not bad, (key, ci, "counts", bad[:2])
+            bad = compare_planes(_render(vrt, engine, sc, st, push, True, PRODUCT), exp, PRODUCT)   # the product march
+            assert not bad, (key, ci, "product", bad[:2])
+    for sc in scenes.values():
+        sc.destroy()
