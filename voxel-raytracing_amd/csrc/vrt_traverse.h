@@ -1138,7 +1138,10 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
 // per-lane iteration of a hit to remember -- a lane's own iteration count (fetches) is its i.
 // Same fp32 additions per lane, in the same order: bit-identical results.  Runs under the EXEC mask it is entered with.
 #ifndef VRT_OWN_CAP
-#define VRT_OWN_CAP 4
+#define VRT_OWN_CAP 4                // iterations of its own a lane may take per look (df_any_loop; measured: DESIGN.md 5)
+#endif
+#ifndef VRT_OWN_CAP_BRICK
+#define VRT_OWN_CAP_BRICK 8          // ... in the brick march, whose look-ups cost more (trace_brick_own: 5.07 ms at 4, 5.00 at 8)
 #endif
 __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
                                             float& x, float& y, float& z, float dx, float dy, float dz,
@@ -1457,13 +1460,13 @@ __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f
                     else { material = m; fetches = i + 1u; }
                     done = true;
                 } else if (clear >= maxSteps - i) { done = true; fetches = maxSteps; }
-                else own = clear < (uint32_t)VRT_OWN_CAP ? clear : (uint32_t)VRT_OWN_CAP;
+                else own = clear < (uint32_t)VRT_OWN_CAP_BRICK ? clear : (uint32_t)VRT_OWN_CAP_BRICK;
             }
         }
         if (__ballot(own != 0u) == 0ull) break;
         const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
 #pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)VRT_OWN_CAP; j++) {
+        for (uint32_t j = 0; j < (uint32_t)VRT_OWN_CAP_BRICK; j++) {
             const uint64_t mk = __ballot(own > j);
             if (mk == 0ull) break;
             dda_advance_live(s, mk);
