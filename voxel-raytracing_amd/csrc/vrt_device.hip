@@ -1479,6 +1479,10 @@ __device__ __forceinline__ float dist2_pk(const float4& a, const float4& b)
     return q.x + q.y;
 }
 
+__device__ __forceinline__ constexpr int r2_of(int tx, int ty) { return tx * tx + ty * ty; }
+// as-shipped taps: (-1,-1) * G2, (1,-1) * G0, (0,0) * G2
+__device__ __forceinline__ constexpr float shipped_lk(int i) { return i == 1 ? 0.0f : 0.36067376022224085f; }
+
 template <bool SHIPPED, int TH>
 __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int R)
 {
@@ -1489,7 +1493,6 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
     {
         int cy = (int)threadIdx.x / RW, cx = (int)threadIdx.x - cy * RW;       // (RW >= 66: cy is 0..3)
         const int dy = 256 / RW, dx = 256 - dy * RW;
-        const float r255 = 1.0f / 255.0f, r127 = 1.0f / 127.0f;
         for (int t = (int)threadIdx.x; t < NP; t += 256) {
             int x = x0 - R + cx, y = y0 - R + cy;
             x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
@@ -1497,8 +1500,10 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
             const size_t i = (size_t)y * (size_t)P.W + (size_t)x;
             const uchar4 c = reinterpret_cast<const uchar4*>(P.color_in)[i];
             const char4 n = reinterpret_cast<const char4*>(P.normal)[i];
-            lc[t] = make_float4((float)c.x * r255, (float)c.y * r255, (float)c.z * r255, (float)c.w * r255);
-            ln[t] = make_float4(fmaxf((float)n.x * r127, -1.0f), fmaxf((float)n.y * r127, -1.0f), fmaxf((float)n.z * r127, -1.0f), fmaxf((float)n.w * r127, -1.0f));
+            // the CODES as floats (SNORM -128 = -127): 1/255 and 1/127 ride in the distances' scale factors, and the output is a
+            // mean of codes already
+            lc[t] = make_float4((float)c.x, (float)c.y, (float)c.z, (float)c.w);
+            ln[t] = make_float4(fmaxf((float)n.x, -127.0f), fmaxf((float)n.y, -127.0f), fmaxf((float)n.z, -127.0f), fmaxf((float)n.w, -127.0f));
             lp[t] = reinterpret_cast<const float4*>(P.position)[i];
             cx += dx; cy += dy;
             if (cx >= RW) { cx -= RW; cy++; }
@@ -1509,6 +1514,7 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
     if (px >= P.W) return;
     constexpr int ntaps = SHIPPED ? 3 : 9;
     const int rowoff = R * RW;
+    const float kc = P.kc * (1.0f / (255.0f * 255.0f)), kn = P.kn * (1.0f / (127.0f * 127.0f));
     for (int ly = (int)(threadIdx.x >> 6); ly < TH; ly += 4) {
         const int py = y0 + ly;
         if (py >= P.H) break;
@@ -1527,18 +1533,26 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
                 const int r2 = tx * tx + ty * ty;
                 kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2);
             }
+            if (tx == 0 && ty == 0) {                            // the centre tap: every distance is 0, its weight is the kernel's
+                s01 += (v2f){sc.x, sc.y} * kern; s23 += (v2f){sc.z, sc.w} * kern; total += kern;
+                continue;
+            }
             const int ci = c0 + ty * rowoff + tx * R;
             const float4 oc = lc[ci], op = lp[ci], on = ln[ci];
-            const float e = __builtin_fmaf(dist2_pk(sp, op), P.kp, __builtin_fmaf(dist2_pk(sc, oc), P.kc, dist2_pk(sn, on) * P.kn));
-            const float wk = __builtin_amdgcn_exp2f(-e) * kern;
+            // the kernel weight rides in the exponent: w * kern = exp2(-(e - log2 kern))
+            const float lk = r2_of(tx, ty) == 0 ? 0.0f : (r2_of(tx, ty) == 1 ? 0.18033688011112042f : 0.36067376022224085f);   // -log2(G1), -log2(G2)
+            const float e = __builtin_fmaf(dist2_pk(sp, op), P.kp, __builtin_fmaf(dist2_pk(sc, oc), kc, __builtin_fmaf(dist2_pk(sn, on), kn, SHIPPED ? shipped_lk(i) : lk)));
+            const float wk = __builtin_amdgcn_exp2f(-e);
             const v2f w2 = {wk, wk};
             s01 = __builtin_elementwise_fma((v2f){oc.x, oc.y}, w2, s01);
             s23 = __builtin_elementwise_fma((v2f){oc.z, oc.w}, w2, s23);
             total += wk;
         }
         const float r = __builtin_amdgcn_rcpf(total);
+        // a weighted mean of codes: round half up, clamp (the weights are positive, the mean cannot leave 0..255 by more than rounding)
         uchar4 out;
-        out.x = unorm8(s01.x * r); out.y = unorm8(s01.y * r); out.z = unorm8(s23.x * r); out.w = unorm8(s23.y * r);
+        out.x = (uint8_t)fminf(floorf(fmaf(s01.x, r, 0.5f)), 255.0f); out.y = (uint8_t)fminf(floorf(fmaf(s01.y, r, 0.5f)), 255.0f);
+        out.z = (uint8_t)fminf(floorf(fmaf(s23.x, r, 0.5f)), 255.0f); out.w = (uint8_t)fminf(floorf(fmaf(s23.y, r, 0.5f)), 255.0f);
         reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
     }
 }
