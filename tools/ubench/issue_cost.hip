@@ -44,6 +44,12 @@ KERNEL(k_exec_iter,  "s_mov_b64 exec, %4\n\t v_min3_u32 %3, %0, %1, %2\n\t v_cmp
 KERNEL(k_vcc_iter,   "v_min3_u32 %3, %0, %1, %2\n\t v_cmp_eq_u32_e64 %4, %3, %0\n\t v_cmp_eq_u32_e64 %5, %3, %1\n\t v_cmp_eq_u32_e64 %6, %3, %2\n\t v_cndmask_b32_e64 v40, 0, %1, %4\n\t v_cndmask_b32_e64 v41, 0, %2, %5\n\t v_cndmask_b32_e64 v42, 0, %0, %6\n\t v_add_f32 %0, %0, v40\n\t v_add_f32 %1, %1, v41\n\t v_add_f32 %2, %2, v42\n\t", "vcc", "v40", "v41", "v42")
 KERNEL(k_rcp,        "v_rcp_f32 %0, %0\n\t", "vcc")
 KERNEL(k_fma,        "v_fma_f32 %0, %0, %1, %2\n\t", "vcc")
+KERNEL(k_pk_fma,     "v_pk_fma_f32 v[40:41], v[42:43], v[44:45], v[40:41]\n\t", "vcc", "v40", "v41", "v42", "v43", "v44", "v45")
+KERNEL(k_pk_mul,     "v_pk_mul_f32 v[40:41], v[42:43], v[44:45]\n\t", "vcc", "v40", "v41", "v42", "v43", "v44", "v45")
+KERNEL(k_pk_add,     "v_pk_add_f32 v[40:41], v[40:41], v[44:45]\n\t", "vcc", "v40", "v41", "v42", "v43", "v44", "v45")
+KERNEL(k_exp,        "v_exp_f32 %0, %0\n\t", "vcc")
+KERNEL(k_floor,      "v_floor_f32 %0, %0\n\t", "vcc")
+KERNEL(k_dsread128,  "ds_read_b128 v[40:43], %0\n\t s_waitcnt lgkmcnt(0)\n\t", "vcc", "v40", "v41", "v42", "v43")
 KERNEL(k_branch,     "s_cmp_eq_u32 s60, 0\n\t s_cbranch_scc1 1f\n\t 1:\n\t", "vcc", "s60", "scc")
 KERNEL(k_branch_taken, "s_branch 1f\n\t s_nop 0\n\t 1:\n\t", "vcc")
 
@@ -55,6 +61,7 @@ int main()
     const int iters = 2000, blocks = 256 * 8;           // 8 blocks of 256 threads per CU: 8 waves per SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<T> tests = {
+        {"v_pk_fma_f32", k_pk_fma, 1}, {"v_pk_mul_f32", k_pk_mul, 1}, {"v_pk_add_f32", k_pk_add, 1}, {"v_exp_f32", k_exp, 1}, {"v_floor_f32", k_floor, 1},
         {"v_add_f32 dependent", k_add_dep, 1}, {"v_add_f32 x2 independent", k_add_ind, 2}, {"v_min3_u32", k_min3, 1},
         {"v_cmpx + v_add (2)", k_cmpx_add, 2}, {"v_cmpx + v_add + s_mov exec (3)", k_cmpx_add_smov, 3},
         {"v_cmp_e64 -> sgpr", k_cmp_sgpr, 1}, {"v_cmp_e32 -> vcc", k_cmp_vcc, 1}, {"v_cndmask_e64 sgpr mask", k_cnd_sgpr, 1},
