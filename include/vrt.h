@@ -138,6 +138,14 @@ void vrt_ctx_destroy(vrt_ctx* ctx);                         /* Engine::destroy *
  * torch's default stream is. */
 int  vrt_ctx_set_stream(vrt_ctx* ctx, void* hip_stream);
 int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle(), engine.cpp:351 */
+/* Development switches of a context (no reference analogue; the reference's counterpart is recompiling a shader): every
+ * one is 1 by default and changes speed only, never a result -- the tests render "the same frame without X" with them.
+ * Names: "tile_tags", "box_rect", "xcd_regions", "fast_loop", "no_bounce_kernel", "sky_fast" (looked at by every
+ * vrt_render_geometry* call) and "open_cells", "df_prefetch", "df_own" (looked at when a scene is created).  The
+ * environment seeds them ONCE, at vrt_ctx_create (VRT_TILE_TAGS=0, VRT_SKY_FAST=0, ...); nothing on the render path
+ * calls getenv.  Unknown name: VRT_ERR_INVALID. */
+int  vrt_ctx_set_option(vrt_ctx* ctx, const char* name, int32_t value);
+int  vrt_ctx_get_option(vrt_ctx* ctx, const char* name, int32_t* value);
 const char* vrt_last_error(void);
 /* Name of the device, compute units, and whether the library was built for its gfx arch. */
 int  vrt_device_info(vrt_ctx* ctx, char* name, size_t name_len, int* compute_units);
@@ -334,6 +342,12 @@ int  vrt_jitter_offset(int32_t index, int32_t phase_count, float* jitter_x, floa
 /* Time of the most recent vrt_render_geometry primary-ray kernel / all its kernels, and of the most
  * recent vrt_denoise, in milliseconds (HIP events on the context stream; blocks until they complete). */
 int  vrt_last_timings(vrt_ctx* ctx, float* primary_ms, float* geometry_ms, float* denoise_ms);
+/* Diagnostic of the sky-texel fast path (csrc/vrt_sky.h; skyColor, voxel_volume.frag:98-105): for n unnormalised
+ * directions (device floats, xyz per direction) the texel skyColor(normalize(v)) reads under the numeric spec and the
+ * one the fast path decides, both computed by the GPU: out[4i] = spec x | y << 16, out[4i+1] = fast x | y << 16,
+ * out[4i+2] = 1 if the fast path is sure of its texel (only then may the two be compared), out[4i+3] = float bits of the
+ * fast coordinate u * sky_w.  tests/test_gpu_sky.py sweeps it over 10^8 directions. */
+int  vrt_debug_sky_texels(vrt_ctx* ctx, const vrt_scene* scene, const float* dirs_dev, size_t n, uint32_t* out_dev);
 /* Enable/disable per-call event recording (default on). */
 int  vrt_ctx_set_timing(vrt_ctx* ctx, int enabled);
 

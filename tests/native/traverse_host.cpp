@@ -80,6 +80,22 @@ void* th_create(const uint8_t* vox, int W, int H, int D)
 
 void th_destroy(void* p) { delete (HostVolume*)p; }
 
+// the host's eligibility test for trace_df_fast's 32-bit layout, and the largest byte offset the loop can form for a volume
+// (64-bit arithmetic; the test compares the two either side of 2^32)
+int th_df_fast_layout_ok(int W, int H, int D) { return df_fast_layout_ok(W, H, D) ? 1 : 0; }
+uint64_t th_df_fast_reach(int W, int H, int D)
+{
+    const uint64_t pwh = ((uint64_t)W + 2u) * ((uint64_t)H + 2u), stride = df_field_bytes(W, H, D);
+    const uint64_t bias = pwh, sentinel = bias + 9u * stride;                    // trace_df_fast: bias, octoff + index, sentinel
+    const uint64_t last_index = ((uint64_t)W + 2u) * ((uint64_t)H + 2u) * ((uint64_t)D + 2u) - 1u;
+    const uint64_t id_read = bias + 8u * stride + last_index;                    // octoff + idx + voxoff
+    const uint64_t prefetch = bias + 7u * stride + last_index + pwh;             // a live lane's index + one slice
+    uint64_t m = sentinel;
+    if (id_read > m) m = id_read;
+    if (prefetch > m) m = prefetch;
+    return m;
+}
+
 } // extern "C"
 
 // ---- brick scenes: the two-level clearance of vrt_scene_from_bricks, built here by plain definitions -----------------------

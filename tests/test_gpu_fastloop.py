@@ -1,5 +1,5 @@
 """The hand-written look-up loop (vrt_traverse.h trace_df_fast; chosen by the host for AUTO / DF when the budgets are <= 1024
-and no hit_voxel plane is asked for) against the oracle and against the general loop (VRT_FAST_LOOP=0): primary rays and the
+and no hit_voxel plane is asked for) against the oracle and against the general loop (context option fast_loop = 0): primary rays and the
 secondary rays of the megakernel / split kernels (partly filled waves), ties, axis-parallel rays, cameras inside the volume
 and on lattice points, rays that miss the box, budgets of 1 ... 1024, ragged frame sizes, batches, and a randomised sweep."""
 import os
@@ -23,16 +23,9 @@ def _render(vrt, engine, sc, st, push, fast, planes=PLANES):
     gb = vrt.GeometryBuffer(engine, W, H, planes)
     stc, fr = st.to_c(), gb.to_c()
     import ctypes as C
-    old = os.environ.get("VRT_FAST_LOOP")
-    os.environ["VRT_FAST_LOOP"] = "1" if fast else "0"
-    try:
+    with engine.options(fast_loop=fast):
         vrt._capi.check(vrt.lib().vrt_render_geometry(engine.ctx, sc.handle, C.byref(push), C.byref(stc), C.byref(fr), None))
         engine.synchronize()
-    finally:
-        if old is None:
-            os.environ.pop("VRT_FAST_LOOP", None)
-        else:
-            os.environ["VRT_FAST_LOOP"] = old
     return gb.numpy()
 
 
@@ -187,14 +180,8 @@ def test_secondary_ray_loops_agree(vrt, oracle, engine):
     sky, noise = vrt.synthetic.sky_gradient(32, 16), vrt.synthetic.blue_noise_standin(32)
     scenes = {}
     for own, pf in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
-        old = {k: os.environ.get(k) for k in ("VRT_DF_OWN", "VRT_DF_PREFETCH")}
-        os.environ["VRT_DF_OWN"], os.environ["VRT_DF_PREFETCH"] = own, pf
-        try:
+        with engine.options(df_own=int(own), df_prefetch=int(pf)):
             scenes[(own, pf)] = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
-        finally:
-            for k, v in old.items():
-                if v is None: os.environ.pop(k, None)
-                else: os.environ[k] = v
     osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
     for ci, (pos, yaw, pitch, ao, ao_steps, max_steps) in enumerate((((32.3, 30.1, -40.0), 90.0, 0.0, 4, 64, 512), ((10.0, 50.0, 10.0), 45.0, -30.0, 3, 16, 200),
                                                                       ((32.0, 20.0, 32.0), 10.0, 5.0, 5, 1, 37), ((80.0, 70.0, -30.0), 130.0, -25.0, 2, 64, 1000))):

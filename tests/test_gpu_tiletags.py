@@ -1,6 +1,6 @@
 """Tile tags (k_tile_tags: the 8x8-pixel blocks no occupied 4^3 cell projects onto write what a miss writes without tracing) and
 open cells (a ray ends as a miss where nothing solid is left in its octant): the frames they produce against the frames
-without either (VRT_TILE_TAGS=0 at launch, VRT_OPEN_CELLS=0 at scene build) and against the oracle -- every traversal mode
+without either (context options tile_tags = 0 at launch -- which also switches the sky-texel fast path off --, open_cells = 0 at scene build) and against the oracle -- every traversal mode
 (8x8 and 16x16 workgroup tiles), cameras at all kinds of angles and distances, jitter, ragged sizes, batches in kernel
 arguments and in the table, sharded launches, split kernels -- and a check that blocks really are skipped."""
 import ctypes as C
@@ -17,26 +17,13 @@ GB = ["color8", "depth", "motion", "mask8", "position", "normal8"]
 PRODUCT = GB + ["color_f", "hit_id", "hit_mask", "rays_total"]
 
 
-class _env:
-    def __init__(self, **kv): self.kv = kv
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
-
-
 def _render(vrt, engine, sc, st, push, tags, planes=PRODUCT, shard=None, flags=None):
     W, H = st.renderResolution()
     gb = vrt.GeometryBuffer(engine, W, H, planes)
     stc, fr = st.to_c(), gb.to_c()
     if flags is not None:
         stc.flags = flags
-    with _env(VRT_TILE_TAGS="1" if tags else "0"):
+    with engine.options(tile_tags=tags, sky_fast=tags):
         vrt._capi.check(vrt.lib().vrt_render_geometry(engine.ctx, sc.handle, C.byref(push), C.byref(stc), C.byref(fr),
                                                       C.byref(shard) if shard is not None else None))
         engine.synchronize()
@@ -59,7 +46,7 @@ def test_tags_and_open_cells_change_nothing(vrt, oracle, engine, trav):
         D, H, W = vol.shape
         pal = metallic_palette(vrt)
         sky, noise = vrt.synthetic.sky_gradient(32, 16), vrt.synthetic.blue_noise_standin(32)
-        with _env(VRT_OPEN_CELLS="0"):
+        with engine.options(open_cells=0):
             closed = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
         sc = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
         osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
@@ -88,7 +75,7 @@ def test_tags_skip_blocks_and_open_cells_end_rays(vrt, engine):
     res = (160, 96)
     st = vrt.VoxelRenderSettings.primary_only(res)
     push = camera_push(vrt, (64, 64, 64), res)
-    with _env(VRT_OPEN_CELLS="0"):
+    with engine.options(open_cells=0):
         closed = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt))
     sc = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt))
     planes = ["hit_id", "steps_primary", "steps_total", "rays_total"]
@@ -117,7 +104,7 @@ def test_tags_in_batches_and_sharded_launches(vrt, engine, nranks, strip_rows):
         got = {}
         for tags in (False, True):
             frames = [np.zeros((res[1], res[0], 4), np.uint8) for _ in range(n)]
-            with _env(VRT_TILE_TAGS="1" if tags else "0"):
+            with engine.options(tile_tags=tags, sky_fast=tags):
                 for rank in range(nranks):
                     stage = vrt.GeometryStage(engine, st, sc)
                     gbs = stage.prepare_batch(n, vrt.make_shard(rank, nranks, strip_rows))(pushes)
@@ -141,7 +128,7 @@ def test_open_bricks_and_brick_tags_change_nothing(vrt, engine):
     pal = metallic_palette(vrt)
     sky, noise = vrt.synthetic.sky_gradient(32, 16), vrt.synthetic.blue_noise_standin(32)
     grid, pool = vrt.synthetic.bricks_from_dense(vol)
-    with _env(VRT_OPEN_CELLS="0"):
+    with engine.options(open_cells=0):
         closed = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky, noise=noise)
         bclosed = vrt.VoxelScene.from_bricks(engine, grid, pool, pal, sky=sky, noise=noise)
     bsc = vrt.VoxelScene.from_bricks(engine, grid, pool, pal, sky=sky, noise=noise)

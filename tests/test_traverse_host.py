@@ -147,3 +147,26 @@ def test_brick_march_matches_oracle_random_rays(th, oracle, seed, dims, fill):
         assert (any_out[:, 0] == exp[:, 0]).all() and (any_out[:, 11] == exp[:, 11]).all(), max_steps
         assert lk2.value <= lk.value
     th.thb_destroy(h)
+
+
+def test_df_fast_layout_predicate_covers_every_offset(th):
+    """The hand-written look-up loop forms 32-bit offsets from (W+2)(H+2) bytes in front of field 0; the host may only choose
+    it while the largest of them (the 0xFF byte, a hit's id read, a prefetch one slice on) stays below 2^32.  Sizes either
+    side of the boundary, the advisor's two (1498x1498x210, 480x480x2052) included: the old test 9*ndf + 256 <= 2^32 - 1
+    accepted both although the sentinel offset wraps."""
+    th.th_df_fast_layout_ok.argtypes = [C.c_int, C.c_int, C.c_int]
+    th.th_df_fast_reach.restype = C.c_uint64
+    th.th_df_fast_reach.argtypes = [C.c_int, C.c_int, C.c_int]
+    for dims in [(1498, 1498, 210), (480, 480, 2052), (256, 256, 256), (512, 512, 512), (768, 768, 768), (780, 780, 780),
+                 (781, 781, 781), (4096, 8, 8), (8, 4096, 8), (8, 8, 4096), (2894, 2894, 54), (1, 1, 1)]:
+        ok, reach = th.th_df_fast_layout_ok(*dims), th.th_df_fast_reach(*dims)
+        if ok:
+            assert reach <= 0xFFFFFFFF, (dims, reach)
+            assert (dims[0] + 2) * (dims[1] + 2) < (1 << 23)
+    assert not th.th_df_fast_layout_ok(1498, 1498, 210) and th.th_df_fast_reach(1498, 1498, 210) > 0xFFFFFFFF
+    assert not th.th_df_fast_layout_ok(480, 480, 2052) and th.th_df_fast_reach(480, 480, 2052) > 0xFFFFFFFF
+    assert th.th_df_fast_layout_ok(256, 256, 256) and th.th_df_fast_layout_ok(512, 512, 512)
+    # a sweep across the boundary along one axis: the predicate never accepts a volume whose reach wraps
+    for d in range(1900, 2100, 3):
+        if th.th_df_fast_layout_ok(480, 480, d):
+            assert th.th_df_fast_reach(480, 480, d) <= 0xFFFFFFFF, d

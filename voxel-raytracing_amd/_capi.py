@@ -124,6 +124,9 @@ SYMBOLS = {
     "vrt_jitter_offset": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vrt_last_timings": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vrt_ctx_set_timing": (C.c_int, [_P, C.c_int]),
+    "vrt_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "vrt_ctx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
+    "vrt_debug_sky_texels": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
 }
 
 _lib = None

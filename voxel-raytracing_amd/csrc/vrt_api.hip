@@ -36,8 +36,32 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 } // namespace
 
+// Development switches of a context: A/B experiments and the tests' "the same frame without X" runs.  Every one defaults to on
+// and changes speed only, never a result.  Seeded ONCE, at vrt_ctx_create, from the environment (VRT_TILE_TAGS=0 ...); nothing
+// on the render path reads the environment.  vrt_ctx_set_option changes them per context.
+struct DevOptions {
+    int tile_tags = 1;         // k_tile_tags ahead of K1
+    int box_rect = 1;          // the frame's box rectangle
+    int xcd_regions = 1;       // launches of >= 8 unsharded frames: one screen region per XCD and frame
+    int fast_loop = 1;         // AUTO / DF through the hand-written look-up loop
+    int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
+    int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
+    int open_cells = 1;        // (scene build) open cells / open bricks in the clearance fields
+    int df_prefetch = 1;       // (scene build) secondary rays' look-ups prefetch the neighbouring rows
+    int df_own = 1;            // (scene build) AO rays spend their own clearance
+};
+struct OptName { const char* name; const char* env; int DevOptions::*field; };
+static const OptName kOptNames[] = {
+    {"tile_tags", "VRT_TILE_TAGS", &DevOptions::tile_tags}, {"box_rect", "VRT_BOX_RECT", &DevOptions::box_rect},
+    {"xcd_regions", "VRT_XCD_REGIONS", &DevOptions::xcd_regions}, {"fast_loop", "VRT_FAST_LOOP", &DevOptions::fast_loop},
+    {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
+    {"open_cells", "VRT_OPEN_CELLS", &DevOptions::open_cells}, {"df_prefetch", "VRT_DF_PREFETCH", &DevOptions::df_prefetch},
+    {"df_own", "VRT_DF_OWN", &DevOptions::df_own},
+};
+
 struct vrt_ctx {
     int device = 0;
+    DevOptions opt;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     bool timing = true;
@@ -85,6 +109,7 @@ struct vrt_scene {
     float* sky = nullptr;
     uint8_t* noise = nullptr;
     float* sky_normals = nullptr;
+    uint32_t* sky8 = nullptr;
     uint32_t occ2_bytes = 0, occ3_bytes = 0;
     // brick scenes
     uint32_t* bgrid = nullptr; uint8_t* bcoarse = nullptr; uint8_t* bpool = nullptr; uint8_t* bfine = nullptr;
@@ -108,6 +133,10 @@ int vrt_ctx_create(int device, vrt_ctx** out)
     HIPCHK(hipSetDevice(device));
     vrt_ctx* c = new vrt_ctx();
     c->device = device;
+    for (const OptName& o : kOptNames) {                       // the one place the environment is read
+        const char* e = getenv(o.env);
+        if (e && e[0] == '0') c->opt.*(o.field) = 0;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(VRT_ERR_HIP, "hipStreamCreate failed"); }
     hipEventCreate(&c->ev_geo0); hipEventCreate(&c->ev_prim1); hipEventCreate(&c->ev_geo1);
     hipEventCreate(&c->ev_den0); hipEventCreate(&c->ev_den1);
@@ -155,6 +184,22 @@ int vrt_ctx_synchronize(vrt_ctx* c)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     return VRT_OK;
+}
+
+int vrt_ctx_set_option(vrt_ctx* c, const char* name, int32_t value)
+{
+    if (!c || !name) return fail(VRT_ERR_INVALID, "vrt_ctx_set_option: NULL argument");
+    for (const OptName& o : kOptNames)
+        if (strcmp(o.name, name) == 0) { c->opt.*(o.field) = value != 0 ? 1 : 0; return VRT_OK; }
+    return fail(VRT_ERR_INVALID, std::string("vrt_ctx_set_option: unknown option '") + name + "'");
+}
+
+int vrt_ctx_get_option(vrt_ctx* c, const char* name, int32_t* value)
+{
+    if (!c || !name || !value) return fail(VRT_ERR_INVALID, "vrt_ctx_get_option: NULL argument");
+    for (const OptName& o : kOptNames)
+        if (strcmp(o.name, name) == 0) { *value = c->opt.*(o.field); return VRT_OK; }
+    return fail(VRT_ERR_INVALID, std::string("vrt_ctx_get_option: unknown option '") + name + "'");
 }
 
 int vrt_ctx_set_timing(vrt_ctx* c, int enabled)
@@ -235,6 +280,7 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->sky) hipFree(s->sky);
     if (s->noise) hipFree(s->noise);
     if (s->sky_normals) hipFree(s->sky_normals);
+    if (s->sky8) hipFree(s->sky8);
     if (s->bgrid) hipFree(s->bgrid);
     if (s->bcoarse) hipFree(s->bcoarse);
     if (s->bpool) hipFree(s->bpool);
@@ -251,8 +297,14 @@ int vrt_scene_set_sky(vrt_ctx* c, vrt_scene* s, const float* rgba, uint32_t w, u
     size_t bytes = (size_t)w * h * 16;
     HIPCHK(hipMalloc((void**)&d, bytes));
     HIPCHK(hipMemcpy(d, rgba, bytes, hipMemcpyHostToDevice));
+    uint32_t* d8 = nullptr;
+    { hipError_t e8 = hipMalloc((void**)&d8, (size_t)w * h * 4); if (e8 != hipSuccess) { hipFree(d); return fail(VRT_ERR_HIP, std::string("hipMalloc (sky RGBA8): ") + hipGetErrorString(e8)); } }
     if (s->sky) hipFree(s->sky);
+    if (s->sky8) hipFree(s->sky8);
     s->sky = d; s->d.sky = d; s->d.sky_w = w; s->d.sky_h = h;
+    // the sky as the colour target stores a miss, and the constants of the texel fast path (vrt_sky.h)
+    s->sky8 = d8; s->d.sky8 = d8; s->d.skyk = sky_fast_consts(w, h);
+    HIPCHK(launch_sky_rgba8(d, d8, (size_t)w * h, c->stream));
     // skyColor of the normals a hit can have (calcAmbient's sky tint, frag:224): 64 x float4, by the shading code itself
     if (!s->sky_normals) HIPCHK(hipMalloc((void**)&s->sky_normals, 64 * 4 * sizeof(float)));
     s->d.sky_normals = s->sky_normals;
@@ -377,7 +429,7 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
     // eight clearance fields, and -- while 32-bit offsets reach all of it -- a ninth field with the voxel ids in the same
     // layout plus one byte 0xFF behind it (trace_df_fast)
     {
-        const bool fast = 9ull * ndf + 256ull <= 0xFFFFFFFFull && ((uint64_t)W + 2u) * ((uint64_t)H + 2u) < (1ull << 23);
+        const bool fast = df_fast_layout_ok(d.W, d.H, d.D);
         const size_t bytes = fast ? 9 * ndf + 256 : 8 * ndf;
         s->df_guard = ((((size_t)W + 2u) * ((size_t)H + 2u)) * 2u + 511u) & ~(size_t)255u;
         {
@@ -419,17 +471,14 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
         }
     }
     {
-        const char* e = getenv("VRT_OPEN_CELLS");                          // development switch: 0 = fields without open cells
-        s->open_cells = !(e && e[0] == '0');
+        s->open_cells = c->opt.open_cells != 0;                           // development switch: 0 = fields without open cells
         SCHK(build_fields(c, s, s->df, s->open_cells));
     }
 #undef SCHK
     d.vox = s->vox; d.occ1 = s->occ1; d.occ2 = s->occ2; d.occ3 = s->occ3; d.df = s->df; d.df_stride = ndf; s->d.palette = s->palette;
     {
-        const char* e = getenv("VRT_DF_PREFETCH");                         // development switch: 0 = no neighbour-row prefetch in the secondary rays' look-ups
-        d.df_prefetch = (d.df_fast && !(e && e[0] == '0')) ? 1u : 0u;
-        const char* o = getenv("VRT_DF_OWN");                              // development switch: 0 = the AO rays through the wave-minimum loop too
-        d.df_own = (d.df_fast && !(o && o[0] == '0')) ? 1u : 0u;
+        d.df_prefetch = (d.df_fast && c->opt.df_prefetch) ? 1u : 0u;       // development switch: 0 = no neighbour-row prefetch in the secondary rays' look-ups
+        d.df_own = (d.df_fast && c->opt.df_own) ? 1u : 0u;                 // development switch: 0 = the AO rays through the wave-minimum loop too
     }
     s->occ2_bytes = (uint32_t)(n2pad * 8); s->occ3_bytes = (uint32_t)(n3pad * 8);
     {
@@ -503,12 +552,10 @@ int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32
     SCHK(launch_build_df(occ, (int)nbx, (int)nby, (int)nbz, s->bcoarse, cstride, tmp0, tmp1, c->stream, 16));
     // open bricks (bit 7): no occupied brick left between here and the volume's corner in the octant's direction
     {
-        const char* e = getenv("VRT_OPEN_CELLS");                          // development switch: 0 = no open bricks
-        s->open_cells = !(e && e[0] == '0');
+        s->open_cells = c->opt.open_cells != 0;                           // development switch: 0 = no open bricks
         if (s->open_cells) SCHK(launch_open_cells(occ, (int)nbx, (int)nby, (int)nbz, s->bcoarse, cstride, tmp0, tmp1, c->stream, 0x80));
         d.brick_open = s->open_cells ? 1u : 0u;
-        const char* o = getenv("VRT_DF_OWN");                              // development switch: 0 = the AO rays through the wave-minimum loop too
-        d.df_own = !(o && o[0] == '0') ? 1u : 0u;
+        d.df_own = c->opt.df_own ? 1u : 0u;                                // development switch: 0 = the AO rays through the wave-minimum loop too
     }
     // the occupied bricks as a list of 8^3 cells, for the tile tags of a launch
     if (n_bricks <= (4u << 20)) {
@@ -553,7 +600,7 @@ bad:
 int vrt_scene_memory(const vrt_scene* s, uint64_t* bytes)
 {
     if (!s || !bytes) return fail(VRT_ERR_INVALID, "vrt_scene_memory: NULL argument");
-    *bytes = s->bytes + (uint64_t)s->d.sky_w * s->d.sky_h * 16u + (uint64_t)s->d.noise_w * s->d.noise_h * 4u + 64u * 16u;
+    *bytes = s->bytes + (uint64_t)s->d.sky_w * s->d.sky_h * 20u + (uint64_t)s->d.noise_w * s->d.noise_h * 4u + 64u * 16u;
     return VRT_OK;
 }
 
@@ -853,8 +900,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     }
     FrameSlot* slots = p.slot;
     int tab = -1;
-    const char* box_env = getenv("VRT_BOX_RECT");                      // development switch: 0 = every wave tests the box
-    const bool box_off = box_env && box_env[0] == '0';
+    const bool box_off = c->opt.box_rect == 0;                         // development switch: every wave tests the box
     if (n > VRT_MAX_BATCH) {
         rc = next_table(c, &tab);
         if (rc != VRT_OK) return rc;
@@ -883,8 +929,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     p.wgs_per_frame_rcp = p.wgs_per_frame ? (uint32_t)(0x100000000ull / (uint64_t)p.wgs_per_frame) : 0u;
     // launches of 8 or more unsharded frames: one screen region per XCD and frame, rotating (block_to_tile, xcd_turn == 2)
     {
-        const char* e = getenv("VRT_XCD_REGIONS");                       // development switch: 0 = off
-        const bool want = !(e && e[0] == '0');
+        const bool want = c->opt.xcd_regions != 0;                       // development switch
         if (want && n >= 8 && p.sh.nranks == 1 && p.tile_h == 8 && p.tiles_x >= 4 && p.tiles_y_local >= 8) {
             const uint32_t rw = ((uint32_t)p.tiles_x + 1u) / 2u, rh = ((uint32_t)p.tiles_y_local + 3u) / 4u;
             p.xcd_turn = 2;
@@ -899,18 +944,25 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     p.tps_rcp = (uint32_t)(0x100000000ull / (uint64_t)p.tps);
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && (st->max_bounces == 0 || !s->metallic_voxels)) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
-    p.no_bounce = (st->max_bounces == 0 || !s->metallic_voxels) && !(getenv("VRT_NO_BOUNCE_KERNEL") && getenv("VRT_NO_BOUNCE_KERNEL")[0] == '0') ? 1 : 0;
+    p.no_bounce = ((st->max_bounces == 0 || !s->metallic_voxels) && c->opt.no_bounce_kernel) ? 1 : 0;
     // default traversal and budgets the recovery of positions from sideDist is exact for: the hand-written look-up loop
     // (vrt_traverse.h trace_df_fast) for every ray of the frame
     {
-        const char* e = getenv("VRT_FAST_LOOP");                          // development switch: 0 = off
-        const bool want = !(e && e[0] == '0');
+        const bool want = c->opt.fast_loop != 0;                          // development switch
         const bool df = st->traversal == VRT_TRAVERSAL_AUTO || st->traversal == VRT_TRAVERSAL_DF;
         const bool sec = p.fused_shade != 1;
         bool ok = want && df && s->d.vol.df_fast && st->max_steps >= 1 && st->max_steps <= 1024 && p.tile_h == 8 &&
                   !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (!sec || st->ao_samples == 0 || (st->ao_steps >= 1 && st->ao_steps <= 1024));
         for (int f = 0; f < n && ok; f++) ok = frames[f].hit_voxel == nullptr;      // the fast loop keeps no mapPos: no hit_voxel plane
         p.fast_loop = ok ? 1 : 0;
+    }
+    // the sky texel of waves that cannot hit anything by vrt_sky.h: launches whose frames hold the reference's targets only
+    // (a diagnostic plane wants values the short path does not make), pixel offsets that fit 32 bits, a sky the bound admits
+    {
+        bool ok = c->opt.sky_fast != 0 && s->d.skyk.w != 0u && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (uint64_t)W * (uint64_t)H < (1ull << 28);
+        for (int f = 0; f < n && ok; f++)
+            ok = !frames[f].color_f && !frames[f].hit_voxel && !frames[f].hit_mask && !frames[f].steps_primary && !frames[f].steps_total && !frames[f].rays_total;
+        p.sky_fast = ok ? 1 : 0;
     }
     p.occ2_bytes = s->occ2_bytes; p.occ3_bytes = s->occ3_bytes;
     p.occ_in_lds = ((size_t)s->occ2_bytes + s->occ3_bytes <= 65536) ? 1 : 0;
@@ -947,8 +999,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     if (c->timing) HIPCHK(hipEventRecord(c->ev_geo0, c->stream));
     // tile tags: dense scenes, frames with a box rectangle, launches that do not report the reference's iteration counts
     {
-        const char* e = getenv("VRT_TILE_TAGS");                          // development switch: 0 = off
-        bool want = !(e && e[0] == '0') && s->cells_ok && !counts && W <= 8128 && H <= 8128;
+        bool want = c->opt.tile_tags != 0 && s->cells_ok && !counts && W <= 8128 && H <= 8128;
         bool any = false;
         for (int f = 0; f < n && want && !any; f++) any = !(slots[f].box[0] == 0 && slots[f].box[1] == 255 && slots[f].box[2] == 0 && slots[f].box[3] == 255);
         const bool tags = want && any;
@@ -1401,6 +1452,14 @@ int vrt_gather_strips(vrt_ctx* c, vrt_comm* k, int32_t root, const void* send, v
 }
 
 // ---- instrumentation -------------------------------------------------------------------------------
+
+int vrt_debug_sky_texels(vrt_ctx* c, const vrt_scene* s, const float* dirs_dev, size_t n, uint32_t* out_dev)
+{
+    if (!c || !s || !dirs_dev || !out_dev) return fail(VRT_ERR_INVALID, "vrt_debug_sky_texels: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_debug_sky(s->d, dirs_dev, n, out_dev, c->stream));
+    return VRT_OK;
+}
 
 int vrt_last_timings(vrt_ctx* c, float* primary_ms, float* geometry_ms, float* denoise_ms)
 {

@@ -432,6 +432,46 @@ hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s)
     return hipGetLastError();
 }
 
+// the sky as the colour target stores it: unorm8 of r, g, b per texel (a = 0, canonical rule F)
+__global__ __launch_bounds__(256) void k_sky_rgba8(const float4* __restrict__ sky, uint32_t* __restrict__ sky8, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 t = sky[i];
+    sky8[i] = (uint32_t)unorm8(t.x) | ((uint32_t)unorm8(t.y) << 8) | ((uint32_t)unorm8(t.z) << 16);
+}
+
+hipError_t launch_sky_rgba8(const float* sky, uint32_t* sky8, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sky_rgba8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(sky), sky8, n);
+    return hipGetLastError();
+}
+
+// Diagnostic (vrt_debug_sky_texels): for n unnormalised directions the sky texel by the numeric spec (sky_color's own
+// arithmetic) and by the fast path, as the hardware computes both: out[4i] = spec x | y << 16, [4i+1] = fast x | y << 16,
+// [4i+2] = the fast path is sure, [4i+3] = float bits of the fast u * sky_w
+__global__ __launch_bounds__(256) void k_debug_sky(const DevScene s, const float* __restrict__ v, size_t n, uint32_t* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float vx = v[3 * i], vy = v[3 * i + 1], vz = v[3 * i + 2];
+    const f3 d = normalize3(mk3(vx, vy, vz));
+    const float u = atan2_spec(d.z, d.x) * 0.1591f + 0.5f;
+    const float w = asin_spec(-d.y) * 0.3183f + 0.5f;
+    const uint32_t sx = wrap_texel(u, s.sky_w), sy = wrap_texel(w, s.sky_h);
+    uint32_t tx = 0u, ty = 0u;
+    float un = 0.0f, vn = 0.0f;
+    const bool sure = s.skyk.w != 0u && sky_texel_fast(vx, vy, vz, s.skyk, tx, ty, un, vn);
+    out[4 * i] = sx | (sy << 16); out[4 * i + 1] = tx | (ty << 16); out[4 * i + 2] = sure ? 1u : 0u; out[4 * i + 3] = __float_as_uint(un);
+}
+
+hipError_t launch_debug_sky(const DevScene& sc, const float* v, size_t n, uint32_t* out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_debug_sky, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc, v, n, out);
+    return hipGetLastError();
+}
+
 // fragmentNoiseSeq + randomDir, voxel_volume.frag:80-95
 __device__ __forceinline__ f3 random_dir(const DevScene& s, const vrt_push& pc, PixCtx& c, uint32_t num)
 {
@@ -474,8 +514,8 @@ __device__ __forceinline__ f3 primary_dir(const FrameSlot& S, int px, int py)
 //    numbers whose exponents differ by less than 96 and whose quotient is normal: guaranteed here for a whole wave by
 //    2^-40 <= min |component| and length <= 2^40 (a component never exceeds the length by more than rounding).  Any other
 //    wave -- zero components, huge or tiny camera vectors, NaN -- takes normalize3.
-__device__ __forceinline__ f3 primary_dir_fast(const RayGenConsts& g, float crx, float cry, float crz, float rcp_w, float rcp_h,
-                                               int fast_screen_div, int px, int py)
+__device__ __forceinline__ f3 primary_v(const RayGenConsts& g, float crx, float cry, float crz, float rcp_w, float rcp_h,
+                                        int fast_screen_div, int px, int py)
 {
     float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     float qx, qy;
@@ -486,7 +526,12 @@ __device__ __forceinline__ f3 primary_dir_fast(const RayGenConsts& g, float crx,
     float vx = ((g.cd.x + sx * crx) + sy * g.planeV.x) + g.jx;
     float vy = ((g.cd.y + sx * cry) + sy * g.planeV.y) + g.jy;
     float vz = ((g.cd.z + sx * crz) + sy * g.planeV.z) + 0.0f;
-    const f3 v = mk3(vx, vy, vz);
+    return mk3(vx, vy, vz);
+}
+// ... and its normalize()
+__device__ __forceinline__ f3 primary_normalize(const f3 v)
+{
+    const float vx = v.x, vy = v.y, vz = v.z;
     const float l = len3(v);
     const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(vx), __builtin_fabsf(vy)), __builtin_fabsf(vz));
     const bool tame = lo >= 0x1p-40f && l <= 0x1p40f;
@@ -631,6 +676,17 @@ template <int N> __device__ __forceinline__ void table_read(const GeomParams& P,
     for (int i = 0; i < N; i++) tmp[i] = w[i];
     __builtin_memcpy(dst, tmp, sizeof tmp);
 }
+// The kernel's own arguments (GeomParams is the one argument, at offset 0 of the segment) as words to be read NOW: the
+// compiler hoists ordinary argument loads to the top of the kernel, where each costs scalar registers across ray generation;
+// what only a rare or late branch needs is read through this pointer, which it cannot see through.
+__device__ __forceinline__ const_u32_ptr kernarg_words(size_t byte_offset)
+{
+    const_u32_ptr p = (const_u32_ptr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset);
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// the planes a miss pixel is stored to (the fast sky wave reads these eight pointers, not all fourteen)
+struct MissPlanes { uint8_t* color8; float* depth; float* motion; uint8_t* mask8; float* position; int8_t* normal8; uint8_t* hit_id; uint8_t* color8_strips; };
 template <bool TABLE> struct SlotOf;
 template <> struct SlotOf<false> {
     static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank, uint32_t& box)
@@ -643,6 +699,18 @@ template <> struct SlotOf<false> {
         shard_rank = S.shard_rank;
     }
     static __device__ __forceinline__ vrt_frame planes(const GeomParams& P, uint32_t frame) { return P.slot[frame].fr; }
+    static __device__ __forceinline__ MissPlanes miss_planes(const GeomParams& P, uint32_t frame)
+    {
+        // (read late, like the fast path's other constants: through a pointer into the arguments the compiler cannot hoist from)
+        const_u32_ptr fp = kernarg_words(offsetof(GeomParams, slot) + (size_t)frame * sizeof(FrameSlot) + offsetof(FrameSlot, fr));
+        MissPlanes m;
+        uint32_t tmp[16];
+#pragma unroll
+        for (int q = 0; q < 12; q++) tmp[q] = fp[q];
+        tmp[12] = fp[14]; tmp[13] = fp[15]; tmp[14] = fp[26]; tmp[15] = fp[27];
+        __builtin_memcpy(&m, tmp, sizeof m);
+        return m;
+    }
     static __device__ __forceinline__ const vrt_push* push(const GeomParams& P, uint32_t frame) { return &P.slot[frame].pc; }
 };
 // The table form reads the pieces when they are needed, like the kernel-argument form does: a copy of the whole slot at the
@@ -661,6 +729,16 @@ template <> struct SlotOf<true> {
         vrt_frame f;
         table_read<sizeof(vrt_frame) / 4>(P, frame, offsetof(FrameSlot, fr), &f);
         return f;
+    }
+    static __device__ __forceinline__ MissPlanes miss_planes(const GeomParams& P, uint32_t frame)
+    {
+        // color8 .. normal8 are the first six pointers of vrt_frame, hit_id the eighth, color8_strips the fourteenth
+        static_assert(offsetof(vrt_frame, normal8) == 40 && offsetof(vrt_frame, hit_id) == 56 && offsetof(vrt_frame, color8_strips) == 104, "vrt_frame layout");
+        MissPlanes m;
+        table_read<12>(P, frame, offsetof(FrameSlot, fr), &m);
+        table_read<2>(P, frame, offsetof(FrameSlot, fr) + offsetof(vrt_frame, hit_id), &m.hit_id);
+        table_read<2>(P, frame, offsetof(FrameSlot, fr) + offsetof(vrt_frame, color8_strips), &m.color8_strips);
+        return m;
     }
     static __device__ __forceinline__ const vrt_push* push(const GeomParams& P, uint32_t frame) { return &P.table[frame].pc; }
 };
@@ -792,9 +870,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     asm volatile("" : "+s"(g.cd.x), "+s"(g.cd.y), "+s"(g.cd.z), "+s"(g.planeV.x), "+s"(g.planeV.y), "+s"(g.planeV.z), "+s"(g.jx), "+s"(g.jy),
                       "+s"(g.W), "+s"(g.H), "+s"(cpx), "+s"(cpy), "+s"(cpz), "+s"(crx), "+s"(cry), "+s"(crz), "+s"(shard_rank),
                       "+s"(rcp_w), "+s"(rcp_h), "+s"(fast_div));
-    // (the scene scalars the DDA set-up will ask for one by one: requested here, used from these registers later)
-    asm volatile("" :: "s"(P.sc.vol.W), "s"(P.sc.vol.H), "s"(P.sc.vol.D), "s"(P.st.max_steps), "s"(P.sc.vol.df), "s"(P.sc.vol.df_stride),
-                       "s"(P.sc.vol.vox));
     if (!tile_origin(M, ty, tx, shard_rank, x0, y0, yp0)) return;
     constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
     const OccT<kLds> occ = stage_occ<kLds>(P, lds_occ);
@@ -814,18 +889,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
     const DevScene& s = P.sc;
     f3 start = mk3(cpx, cpy, cpz);
-    f3 dir = primary_dir_fast(g, crx, cry, crz, rcp_w, rcp_h, fast_div, px, py);
+    const f3 v = primary_v(g, crx, cry, crz, rcp_w, rcp_h, fast_div, px, py);
     RayHit h; RayInt r;
     // a wave whose 8x8 pixels lie outside the frame's box rectangle (FrameSlot::box, vrt_internal.h box_rect) cannot meet the
     // volume: it writes what a miss writes without testing the box (wave-uniform: the rectangle is in units of 32 pixels) --
     // and inside the rectangle neither can a wave whose block no occupied 4^3 cell of the volume projects onto (k_tile_tags)
     const bool skip = box != 0xFF00FF00u && ((uint32_t)(px0 >> 5) < boxr.x || (uint32_t)(px0 >> 5) >= boxr.y || (uint32_t)(py0 >> 5) < boxr.z ||
                                              (uint32_t)(py0 >> 5) >= boxr.w || untagged != 0u);
+    // ... and of everything normalize(), atan() and asin() compute for such a pixel only the sky TEXEL is ever seen: vrt_sky.h
+    // decides it from the unnormalised direction with a bound on its distance to the spec's own coordinate; a wave in which
+    // some lane lies within that bound of a texel edge goes the long way round, every other wave stores the miss pixel here
+    // (32-bit byte offsets from the plane pointers: one shift per plane instead of a 64-bit address each)
+    f3 dir;
     if (skip) {
+    if (kernarg_words(offsetof(GeomParams, sky_fast))[0] != 0u) {
+        // (the constants are read HERE, through a pointer the compiler cannot see through: hoisted to the top of the kernel with
+        // the other arguments they are ten more scalar registers live across ray generation -- 92 instead of 80, one wave per
+        // SIMD less for every wave of the kernel)
+        SkyFastConsts k;
+        {
+            const_u32_ptr kp = kernarg_words(offsetof(GeomParams, sc) + offsetof(DevScene, skyk));
+            uint32_t tmp[sizeof(SkyFastConsts) / 4];
+#pragma unroll
+            for (int q = 0; q < (int)(sizeof(SkyFastConsts) / 4); q++) tmp[q] = kp[q];
+            __builtin_memcpy(&k, tmp, sizeof k);
+        }
+        uint32_t tx, ty;
+        const bool sure = sky_texel_fast(v.x, v.y, v.z, k, tx, ty);
+        if (__ballot(!sure) == 0ull) {
+            const uint32_t* sky8;
+            {
+                const_u32_ptr sp = kernarg_words(offsetof(GeomParams, sc) + offsetof(DevScene, sky8));
+                uint32_t tmp[2] = {sp[0], sp[1]};
+                __builtin_memcpy(&sky8, tmp, sizeof sky8);
+            }
+            const uint32_t c8 = sky8[ty * k.w + tx];
+            const MissPlanes f = SlotOf<TABLE>::miss_planes(P, frame);
+            const uint32_t i32 = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+            if (f.position) *reinterpret_cast<float4*>(reinterpret_cast<char*>(f.position) + (i32 << 4)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (f.motion) *reinterpret_cast<float2*>(reinterpret_cast<char*>(f.motion) + (i32 << 3)) = make_float2(0.0f, 0.0f);
+            if (f.depth) *reinterpret_cast<float*>(reinterpret_cast<char*>(f.depth) + (i32 << 2)) = 0.0f;
+            if (f.normal8) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(f.normal8) + (i32 << 2)) = 0u;
+            if (f.mask8) f.mask8[i32] = (uint8_t)0;
+            if (f.hit_id) f.hit_id[i32] = (uint8_t)0;
+            if (f.color8) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(f.color8) + (i32 << 2)) = c8;
+            if (f.color8_strips) reinterpret_cast<uint32_t*>(f.color8_strips)[(size_t)(yp0 + (py - y0)) * (size_t)W + (size_t)px] = c8;
+            return;
+        }
+    }
+        dir = primary_normalize(v);
         h.material = 0u; h.dir = dir; h.pos = mk3(0.0f, 0.0f, 0.0f); h.normal = mk3(0.0f, 0.0f, 0.0f); h.ncode = 0xFFFFFFFFu;
         r.material = 0u; r.mask = 0u; r.fetches = 0u; r.mx = r.my = r.mz = 0; r.dbg0 = 1u; r.dbg1 = 0u;
-    } else
-    trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
+    } else {
+        // (the scene scalars the DDA set-up will ask for one by one: requested here, used from these registers later)
+        asm volatile("" :: "s"(P.sc.vol.W), "s"(P.sc.vol.H), "s"(P.sc.vol.D), "s"(P.st.max_steps), "s"(P.sc.vol.df), "s"(P.sc.vol.df_stride),
+                           "s"(P.sc.vol.vox));
+        dir = primary_normalize(v);
+        trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
+    }
     bool hit = h.material != 0;
 
     const vrt_frame f = SlotOf<TABLE>::planes(P, frame);   // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store

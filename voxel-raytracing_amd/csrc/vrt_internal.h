@@ -7,6 +7,7 @@
 
 #include "../../include/vrt.h"
 #include "vrt_traverse.h"
+#include "vrt_sky.h"
 
 namespace vrt {
 
@@ -24,6 +25,10 @@ struct DevScene {
     const float*   sky_normals;   // 64 x float4: skyColor(n) for the 26 normals a hit can have, index = mask | (sx<0)<<3 |
                                   // (sy<0)<<4 | (sz<0)<<5 (k_sky_normals; rebuilt whenever the sky changes)
     const uint8_t* noise; uint32_t noise_w, noise_h;
+    // the sky once more as RGBA8 (unorm8 of every texel's r, g, b; a = 0: what a miss pixel's colour target holds) and the
+    // constants of the texel fast path (vrt_sky.h), both made when the sky is set
+    const uint32_t* sky8;
+    SkyFastConsts  skyk;
 };
 
 struct ShardMap {
@@ -177,6 +182,8 @@ struct GeomParams {
                                //    without the bounce loop and its scratch stack
     int32_t    fast_loop;      // 1: AUTO / DF run the hand-written look-up loop (trace_df_fast; the host checked its preconditions)
     int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
+    int32_t    sky_fast;       // 1: waves that cannot hit anything decide their sky texel by vrt_sky.h and write the miss pixel
+                               //    without normalising the ray (no diagnostic planes in the launch, W * H < 2^28)
     uint32_t   occ2_bytes, occ3_bytes;   // both multiples of 16
     // Tile tags (k_tile_tags, launched ahead of K1): one word per 8x8-pixel block of every frame of the launch, == tile_gen
     // where a primary ray of the block can meet an occupied 4^3 cell of the volume; word tags_per_frame - 1 of a frame ==
@@ -231,6 +238,8 @@ hipError_t launch_brick_grid(const uint32_t* grid, int nbx, int nby, int nbz, ui
 hipError_t launch_brick_fine(const uint32_t* padded, int pbx, int pby, const uint32_t* coord, uint32_t n_bricks, const uint8_t* pool,
                              uint8_t* fine, hipStream_t s);
 hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s);
+hipError_t launch_sky_rgba8(const float* sky, uint32_t* sky8, size_t n, hipStream_t s);
+hipError_t launch_debug_sky(const DevScene& sc, const float* v, size_t n, uint32_t* out, hipStream_t s);
 hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int mark = 0);
 hipError_t launch_tile_tags(const GeomParams& p, hipStream_t s);
 hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst, hipStream_t s);

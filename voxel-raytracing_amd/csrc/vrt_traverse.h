@@ -179,6 +179,15 @@ VRT_HD bool df_small(const VolumeView& v)
 {
     return 8ull * v.df_stride <= 0xFFFFFFFFull && ((uint64_t)v.W + 2u) * ((uint64_t)v.H + 2u) < (1ull << 23);
 }
+// trace_df_fast's layout (nine fields + the 0xFF byte, every offset 32 bits): the loop counts its offsets from `bias` =
+// (W+2)(H+2) bytes IN FRONT of field 0, so the largest offset it forms is bias + 9 * field (the 0xFF byte), a hit's id read
+// reaches bias + 8 * field + index, and a live lane's prefetch one slice (bias bytes) past its own index -- all of it must
+// stay below 2^32, and the padded slice must fit the signed 24-bit multiply of the index recovery.
+VRT_HD bool df_fast_layout_ok(int W, int H, int D)
+{
+    const uint64_t pwh = ((uint64_t)W + 2u) * ((uint64_t)H + 2u);
+    return 2ull * pwh + 9ull * (uint64_t)df_field_bytes(W, H, D) + 256ull <= 0xFFFFFFFFull && pwh < (1ull << 23);
+}
 template <bool SMALL> struct IndexT;
 template <> struct IndexT<true>  { typedef uint32_t type; typedef int32_t stype; };
 template <> struct IndexT<false> { typedef size_t type;   typedef long long stype; };

@@ -252,6 +252,31 @@ class Engine:
         """Per-call HIP event recording inside the library (vrt_last_timings); off for throughput runs."""
         check(lib().vrt_ctx_set_timing(self.ctx, 1 if enabled else 0))
 
+    def set_option(self, name: str, value) -> None:
+        """Development switch of this context (include/vrt.h vrt_ctx_set_option): speed only, never a result."""
+        check(lib().vrt_ctx_set_option(self.ctx, name.encode(), 1 if value else 0))
+
+    def option(self, name: str) -> int:
+        v = C.c_int32()
+        check(lib().vrt_ctx_get_option(self.ctx, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def options(self, **kv):
+        """with engine.options(tile_tags=0, sky_fast=0): ...  -- the switches are put back on exit."""
+        eng = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = {k: eng.option(k) for k in kv}
+                for k, v in kv.items():
+                    eng.set_option(k, v)
+                return eng
+
+            def __exit__(self_, *a):
+                for k, v in self_.old.items():
+                    eng.set_option(k, v)
+        return _Scope()
+
     def last_timings(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         check(lib().vrt_last_timings(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
@@ -480,6 +505,7 @@ _PLANE_SPECS = {
     "position": ("float32", (4,)), "normal8": ("int8", (4,)),
     "color_f": ("float32", (3,)), "hit_id": ("uint8", ()), "hit_voxel": ("int16", (3,)), "hit_mask": ("uint8", ()),
     "steps_primary": ("int32", ()), "steps_total": ("int32", ()), "rays_total": ("int32", ()),
+    "color8_strips": ("uint8", (4,)),      # (allocated at the full frame's size: the packed strips of a rank fill its first rows)
 }
 GBUFFER_PLANES = ("color8", "depth", "motion", "mask8", "position", "normal8")
 DEBUG_PLANES = ("color_f", "hit_id", "hit_voxel", "hit_mask", "steps_primary", "steps_total", "rays_total")
