@@ -836,6 +836,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     const vrt_push* push = &pushes[0];
     int W = push->screen_size[0], H = push->screen_size[1];
     if (W <= 0 || H <= 0 || W > 32768 || H > 32768) return fail(VRT_ERR_INVALID, "vrt_render_geometry: bad screen_size");
+    if ((uint64_t)W * (uint64_t)H >= (1ull << 28))              // K1 addresses a plane with 32-bit byte offsets (16 B per pixel at most)
+        return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: frames of 2^28 pixels and more are not supported (render in strips: vrt_shard)");
     for (int f = 0; f < n; f++) {
         const vrt_push& q = pushes[f];
         if (q.screen_size[0] != W || q.screen_size[1] != H)
@@ -959,7 +961,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     // the sky texel of waves that cannot hit anything by vrt_sky.h: launches whose frames hold the reference's targets only
     // (a diagnostic plane wants values the short path does not make), pixel offsets that fit 32 bits, a sky the bound admits
     {
-        bool ok = c->opt.sky_fast != 0 && s->d.skyk.w != 0u && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (uint64_t)W * (uint64_t)H < (1ull << 28);
+        bool ok = c->opt.sky_fast != 0 && s->d.skyk.w != 0u && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u));
         for (int f = 0; f < n && ok; f++)
             ok = !frames[f].color_f && !frames[f].hit_voxel && !frames[f].hit_mask && !frames[f].steps_primary && !frames[f].steps_total && !frames[f].rays_total;
         p.sky_fast = ok ? 1 : 0;
@@ -985,7 +987,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     if (p.total_tiles == 0) return VRT_OK;
     {
         TileMap& m = p.map;
-        m.flags = st->flags; m.n_frames = p.n_frames; m.xcd_turn = p.xcd_turn;
+        m.flags = (st->flags & 0xFFFFu) | (p.sky_fast ? VRT_MAPFLAG_SKY_FAST : 0u); m.n_frames = p.n_frames; m.xcd_turn = p.xcd_turn;
         m.wgs_per_frame = p.wgs_per_frame; m.wgs_per_frame_rcp = p.wgs_per_frame_rcp;
         m.tiles_x = p.tiles_x; m.tiles_x_rcp = p.tiles_x_rcp; m.tiles_y_local = p.tiles_y_local; m.tiles_y_rcp = p.tiles_y_rcp;
         m.tps = p.tps; m.tps_rcp = p.tps_rcp; m.tile = p.tile_h; m.nranks = p.sh.nranks; m.strip_rows = p.sh.strip_rows;

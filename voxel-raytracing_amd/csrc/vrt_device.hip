@@ -685,20 +685,43 @@ __device__ __forceinline__ const_u32_ptr kernarg_words(size_t byte_offset)
     asm volatile("" : "+s"(p));
     return p;
 }
+// base + 32-bit byte offset as a pointer into GLOBAL memory (address space 1): global_load / global_store with the base in a
+// scalar pair and the offset in one vector register
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T* gptr(const void* base, uint32_t byte_offset)
+{
+    return (__attribute__((address_space(1))) T*)((__attribute__((address_space(1))) char*)base + byte_offset);
+}
+typedef float vrt_f4 __attribute__((ext_vector_type(4)));
+typedef float vrt_f2 __attribute__((ext_vector_type(2)));
 // the planes a miss pixel is stored to (the fast sky wave reads these eight pointers, not all fourteen)
 struct MissPlanes { uint8_t* color8; float* depth; float* motion; uint8_t* mask8; float* position; int8_t* normal8; uint8_t* hit_id; uint8_t* color8_strips; };
 template <bool TABLE> struct SlotOf;
 template <> struct SlotOf<false> {
-    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank, uint32_t& box)
+    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_right, int& shard_rank, uint32_t& box)
     {
         const FrameSlot& S = P.slot[frame];
         box = (uint32_t)S.box[0] | ((uint32_t)S.box[1] << 8) | ((uint32_t)S.box[2] << 16) | ((uint32_t)S.box[3] << 24);
         g = S.rg;
-        cam_pos[0] = S.pc.cam_pos[0]; cam_pos[1] = S.pc.cam_pos[1]; cam_pos[2] = S.pc.cam_pos[2];
         cam_right[0] = S.pc.cam_right[0]; cam_right[1] = S.pc.cam_right[1]; cam_right[2] = S.pc.cam_right[2];
         shard_rank = S.shard_rank;
     }
     static __device__ __forceinline__ vrt_frame planes(const GeomParams& P, uint32_t frame) { return P.slot[frame].fr; }
+    // the camera position: only waves that trace need it, and they read it when they know they do (three scalar registers
+    // less across ray generation for everybody)
+    static __device__ __forceinline__ f3 cam_pos(const GeomParams& P, uint32_t frame)
+    {
+        const_u32_ptr w = kernarg_words(offsetof(GeomParams, slot) + (size_t)frame * sizeof(FrameSlot) + offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_pos));
+        return mk3(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]));
+    }
+    // N plane pointers of the frame starting with field `first` of vrt_frame, read NOW (kernarg_words)
+    template <int N> static __device__ __forceinline__ void ptrs(const GeomParams& P, uint32_t frame, int first, void** out)
+    {
+        const_u32_ptr fp = kernarg_words(offsetof(GeomParams, slot) + (size_t)frame * sizeof(FrameSlot) + offsetof(FrameSlot, fr) + 8u * (size_t)first);
+        uint32_t tmp[2 * N];
+#pragma unroll
+        for (int q = 0; q < 2 * N; q++) tmp[q] = fp[q];
+        __builtin_memcpy(out, tmp, sizeof tmp);
+    }
     static __device__ __forceinline__ MissPlanes miss_planes(const GeomParams& P, uint32_t frame)
     {
         // (read late, like the fast path's other constants: through a pointer into the arguments the compiler cannot hoist from)
@@ -716,11 +739,10 @@ template <> struct SlotOf<false> {
 // The table form reads the pieces when they are needed, like the kernel-argument form does: a copy of the whole slot at the
 // top keeps the fourteen plane pointers in scalar registers through the traversal (82 + 6 SGPRs: one wave per SIMD less).
 template <> struct SlotOf<true> {
-    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_pos, float* cam_right, int& shard_rank, uint32_t& box)
+    static __device__ __forceinline__ void head(const GeomParams& P, uint32_t frame, RayGenConsts& g, float* cam_right, int& shard_rank, uint32_t& box)
     {
         table_read<1>(P, frame, offsetof(FrameSlot, box), &box);
         table_read<sizeof(RayGenConsts) / 4>(P, frame, offsetof(FrameSlot, rg), &g);
-        table_read<3>(P, frame, offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_pos), cam_pos);
         table_read<3>(P, frame, offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_right), cam_right);
         table_read<1>(P, frame, offsetof(FrameSlot, shard_rank), &shard_rank);
     }
@@ -729,6 +751,21 @@ template <> struct SlotOf<true> {
         vrt_frame f;
         table_read<sizeof(vrt_frame) / 4>(P, frame, offsetof(FrameSlot, fr), &f);
         return f;
+    }
+    static __device__ __forceinline__ f3 cam_pos(const GeomParams& P, uint32_t frame)
+    {
+        const_u32_ptr w = (const_u32_ptr)((const char*)(P.table + frame) + offsetof(FrameSlot, pc) + offsetof(vrt_push, cam_pos));
+        asm volatile("" : "+s"(w));
+        return mk3(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]));
+    }
+    template <int N> static __device__ __forceinline__ void ptrs(const GeomParams& P, uint32_t frame, int first, void** out)
+    {
+        const_u32_ptr w = (const_u32_ptr)((const char*)(P.table + frame) + offsetof(FrameSlot, fr) + 8u * (size_t)first);
+        asm volatile("" : "+s"(w));                            // (read NOW: not hoisted to where the slot's head is read)
+        uint32_t tmp[2 * N];
+#pragma unroll
+        for (int q = 0; q < 2 * N; q++) tmp[q] = w[q];
+        __builtin_memcpy(out, tmp, sizeof tmp);
     }
     static __device__ __forceinline__ MissPlanes miss_planes(const GeomParams& P, uint32_t frame)
     {
@@ -822,6 +859,17 @@ template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomPara
 // K1: primary rays
 // ---------------------------------------------------------------------------------------------
 
+// the pixel's colour into color_f (debug), color8 and the packed strips
+__device__ __forceinline__ void store_color(const vrt_frame& f, f3 col, size_t i, uint32_t i32, uint32_t strip_off)
+{
+    if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
+    if (f.color8 || f.color8_strips) {
+        const uint32_t c8 = (uint32_t)unorm8(col.x) | ((uint32_t)unorm8(col.y) << 8) | ((uint32_t)unorm8(col.z) << 16);
+        if (f.color8) *gptr<uint32_t>(f.color8, i32 << 2) = c8;
+        if (f.color8_strips) *gptr<uint32_t>(f.color8_strips, strip_off) = c8;
+    }
+}
+
 // MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
@@ -855,20 +903,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     // ... and so does the frame's part of ray generation (camera, hoisted constants, strip assignment), in one batch
     RayGenConsts g;
-    float cam_pos[3], cam_right[3];
+    float cam_right[3];
     int shard_rank;
     uint32_t box;
-    SlotOf<TABLE>::head(P, frame, g, cam_pos, cam_right, shard_rank, box);
+    SlotOf<TABLE>::head(P, frame, g, cam_right, shard_rank, box);
     asm volatile("" : "+s"(box));
     // (one scalar from here on, not three: past 80 scalar registers a SIMD holds 7 of these waves, not 8)
     const uint32_t untagged = (uint32_t)__builtin_amdgcn_readfirstlane((tag != tile_gen && tag_all != tile_gen) ? 1 : 0);
     const uint4 boxr = make_uint4(box & 0xFFu, (box >> 8) & 0xFFu, (box >> 16) & 0xFFu, box >> 24);
-    float cpx = cam_pos[0], cpy = cam_pos[1], cpz = cam_pos[2];
     float crx = cam_right[0], cry = cam_right[1], crz = cam_right[2];
     float rcp_w = P.rcp_w, rcp_h = P.rcp_h;
     int fast_div = P.fast_screen_div;
     asm volatile("" : "+s"(g.cd.x), "+s"(g.cd.y), "+s"(g.cd.z), "+s"(g.planeV.x), "+s"(g.planeV.y), "+s"(g.planeV.z), "+s"(g.jx), "+s"(g.jy),
-                      "+s"(g.W), "+s"(g.H), "+s"(cpx), "+s"(cpy), "+s"(cpz), "+s"(crx), "+s"(cry), "+s"(crz), "+s"(shard_rank),
+                      "+s"(g.W), "+s"(g.H), "+s"(crx), "+s"(cry), "+s"(crz), "+s"(shard_rank),
                       "+s"(rcp_w), "+s"(rcp_h), "+s"(fast_div));
     if (!tile_origin(M, ty, tx, shard_rank, x0, y0, yp0)) return;
     constexpr bool kLds = OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP);
@@ -888,7 +935,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     size_t i = (size_t)py * (size_t)W + (size_t)px;
 
     const DevScene& s = P.sc;
-    f3 start = mk3(cpx, cpy, cpz);
+    f3 start = mk3(0.0f, 0.0f, 0.0f);
     const f3 v = primary_v(g, crx, cry, crz, rcp_w, rcp_h, fast_div, px, py);
     RayHit h; RayInt r;
     // a wave whose 8x8 pixels lie outside the frame's box rectangle (FrameSlot::box, vrt_internal.h box_rect) cannot meet the
@@ -902,38 +949,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // (32-bit byte offsets from the plane pointers: one shift per plane instead of a 64-bit address each)
     f3 dir;
     if (skip) {
-    if (kernarg_words(offsetof(GeomParams, sky_fast))[0] != 0u) {
-        // (the constants are read HERE, through a pointer the compiler cannot see through: hoisted to the top of the kernel with
-        // the other arguments they are ten more scalar registers live across ray generation -- 92 instead of 80, one wave per
-        // SIMD less for every wave of the kernel)
+    if (M.flags & VRT_MAPFLAG_SKY_FAST) {
+        // (everything the short path reads -- the texel constants, the RGBA8 sky, the eight planes a miss is stored to -- is
+        // requested HERE in one batch, through pointers the compiler cannot see through: hoisted to the top of the kernel with
+        // the other arguments they would be 28 more scalar registers live across ray generation, one wave per SIMD less for
+        // every wave of the kernel; read one after the other where each is used they are three dependent round trips in a
+        // wave that does little else)
         SkyFastConsts k;
+        const uint32_t* sky8;
         {
-            const_u32_ptr kp = kernarg_words(offsetof(GeomParams, sc) + offsetof(DevScene, skyk));
-            uint32_t tmp[sizeof(SkyFastConsts) / 4];
+            const_u32_ptr kp = kernarg_words(offsetof(GeomParams, sc) + offsetof(DevScene, sky8));
+            static_assert(offsetof(DevScene, skyk) == offsetof(DevScene, sky8) + 8 && sizeof(SkyFastConsts) == 40, "sky8 and skyk are read as one block");
+            uint32_t tmp[12];
 #pragma unroll
-            for (int q = 0; q < (int)(sizeof(SkyFastConsts) / 4); q++) tmp[q] = kp[q];
-            __builtin_memcpy(&k, tmp, sizeof k);
+            for (int q = 0; q < 12; q++) tmp[q] = kp[q];
+            __builtin_memcpy(&sky8, tmp, 8);
+            __builtin_memcpy(&k, tmp + 2, sizeof k);
         }
+        const MissPlanes f = SlotOf<TABLE>::miss_planes(P, frame);
         uint32_t tx, ty;
         const bool sure = sky_texel_fast(v.x, v.y, v.z, k, tx, ty);
         if (__ballot(!sure) == 0ull) {
-            const uint32_t* sky8;
-            {
-                const_u32_ptr sp = kernarg_words(offsetof(GeomParams, sc) + offsetof(DevScene, sky8));
-                uint32_t tmp[2] = {sp[0], sp[1]};
-                __builtin_memcpy(&sky8, tmp, sizeof sky8);
-            }
-            const uint32_t c8 = sky8[ty * k.w + tx];
-            const MissPlanes f = SlotOf<TABLE>::miss_planes(P, frame);
+            // (the pointers were assembled from words, so the compiler no longer knows they are global memory: say so, or every
+            // access below is a flat instruction with a 64-bit address in two vector registers)
+            const uint32_t c8 = *gptr<const uint32_t>(sky8, (ty * k.w + tx) << 2);
             const uint32_t i32 = (uint32_t)py * (uint32_t)W + (uint32_t)px;
-            if (f.position) *reinterpret_cast<float4*>(reinterpret_cast<char*>(f.position) + (i32 << 4)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (f.motion) *reinterpret_cast<float2*>(reinterpret_cast<char*>(f.motion) + (i32 << 3)) = make_float2(0.0f, 0.0f);
-            if (f.depth) *reinterpret_cast<float*>(reinterpret_cast<char*>(f.depth) + (i32 << 2)) = 0.0f;
-            if (f.normal8) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(f.normal8) + (i32 << 2)) = 0u;
-            if (f.mask8) f.mask8[i32] = (uint8_t)0;
-            if (f.hit_id) f.hit_id[i32] = (uint8_t)0;
-            if (f.color8) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(f.color8) + (i32 << 2)) = c8;
-            if (f.color8_strips) reinterpret_cast<uint32_t*>(f.color8_strips)[(size_t)(yp0 + (py - y0)) * (size_t)W + (size_t)px] = c8;
+            if (f.position) *gptr<vrt_f4>(f.position, i32 << 4) = (vrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){0.0f, 0.0f};
+            if (f.depth) *gptr<float>(f.depth, i32 << 2) = 0.0f;
+            if (f.normal8) *gptr<uint32_t>(f.normal8, i32 << 2) = 0u;
+            if (f.mask8) *gptr<uint8_t>(f.mask8, i32) = (uint8_t)0;
+            if (f.hit_id) *gptr<uint8_t>(f.hit_id, i32) = (uint8_t)0;
+            if (f.color8) *gptr<uint32_t>(f.color8, i32 << 2) = c8;
+            if (f.color8_strips) *gptr<uint32_t>(f.color8_strips, ((uint32_t)(yp0 + (py - y0)) * (uint32_t)W + (uint32_t)px) << 2) = c8;
             return;
         }
     }
@@ -944,24 +992,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         // (the scene scalars the DDA set-up will ask for one by one: requested here, used from these registers later)
         asm volatile("" :: "s"(P.sc.vol.W), "s"(P.sc.vol.H), "s"(P.sc.vol.D), "s"(P.st.max_steps), "s"(P.sc.vol.df), "s"(P.sc.vol.df_stride),
                            "s"(P.sc.vol.vox));
+        start = SlotOf<TABLE>::cam_pos(P, frame);
         dir = primary_normalize(v);
         trace_ray<TRAV, OccT<kLds>, MODE == 1>(s, occ, start, dir, P.st.max_steps, h, r);   // look-ahead request: primary-only kernel
     }
     bool hit = h.material != 0;
 
-    const vrt_frame f = SlotOf<TABLE>::planes(P, frame);   // by value: the thirteen plane pointers arrive with two scalar loads, not one by one before each store
+    const vrt_frame f = SlotOf<TABLE>::planes(P, frame);   // by value: the fourteen plane pointers arrive with two scalar loads, not one by one before each store
     float depth = 0.0f;
     if (hit) depth = len3(mk3(h.pos.x - start.x, h.pos.y - start.y, h.pos.z - start.z));
-    if (f.depth) f.depth[i] = depth;
-    if (f.motion) reinterpret_cast<float2*>(f.motion)[i] = make_float2(0.0f, 0.0f);
-    if (f.mask8) f.mask8[i] = hit ? (uint8_t)230 : (uint8_t)0;          // unorm8(0.9f) = 230 (tests/test_oracle_kat.py), unorm8(0) = 0
-    if (f.position) reinterpret_cast<float4*>(f.position)[i] = make_float4(h.pos.x, h.pos.y, h.pos.z, 0.0f);
+    // (the reference's targets through 32-bit byte offsets from pointers SAID to be global memory -- the table form assembles
+    // them from words and would otherwise get flat instructions with a 64-bit address each; the host admits frames below
+    // 2^28 pixels)
+    const uint32_t i32 = (uint32_t)i;
+    if (f.depth) *gptr<float>(f.depth, i32 << 2) = depth;
+    if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){0.0f, 0.0f};
+    if (f.mask8) *gptr<uint8_t>(f.mask8, i32) = hit ? (uint8_t)230 : (uint8_t)0;          // unorm8(0.9f) = 230 (tests/test_oracle_kat.py), unorm8(0) = 0
+    if (f.position) *gptr<vrt_f4>(f.position, i32 << 4) = (vrt_f4){h.pos.x, h.pos.y, h.pos.z, 0.0f};
     if (f.normal8) {
-        char4 n = make_char4(0, 0, 0, 0);                                   // miss: normal = 0; a wave without a hit skips the conversions
-        if (hit) { n.x = snorm8(h.normal.x); n.y = snorm8(h.normal.y); n.z = snorm8(h.normal.z); }
-        reinterpret_cast<char4*>(f.normal8)[i] = n;
+        uint32_t n = 0u;                                                    // miss: normal = 0; a wave without a hit skips the conversions
+        if (hit) n = (uint32_t)(uint8_t)snorm8(h.normal.x) | ((uint32_t)(uint8_t)snorm8(h.normal.y) << 8) | ((uint32_t)(uint8_t)snorm8(h.normal.z) << 16);
+        *gptr<uint32_t>(f.normal8, i32 << 2) = n;
     }
-    if (f.hit_id) f.hit_id[i] = (uint8_t)h.material;
+    if (f.hit_id) *gptr<uint8_t>(f.hit_id, i32) = (uint8_t)h.material;
     if (f.hit_voxel) {
         f.hit_voxel[i * 3 + 0] = hit ? (int16_t)r.mx : (int16_t)0;
         f.hit_voxel[i * 3 + 1] = hit ? (int16_t)r.my : (int16_t)0;
@@ -975,6 +1028,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         f.steps_total[i] = (uint32_t)t_begin;
         f.rays_total[i] = (uint32_t)wall_clock64();
     }
+    uint32_t* const steps_total = f.steps_total; uint32_t* const rays_total = f.rays_total;
 
     if (MODE != 0) {                                           // 1: primary only; 2: megakernel; 4: megakernel, nothing can bounce
         f3 col;
@@ -983,18 +1037,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 col = color_main_ray<TRAV, OccT<kLds>, MODE != 4>(P, occ, c, h);
-                if (f.steps_total && !(P.st.flags & 3u)) f.steps_total[i] = r.fetches + c.fetches;
-                if (f.rays_total && !(P.st.flags & 3u)) f.rays_total[i] = 1u + c.rays;
+                if (steps_total && !(P.st.flags & 3u)) steps_total[i] = r.fetches + c.fetches;
+                if (rays_total && !(P.st.flags & 3u)) rays_total[i] = 1u + c.rays;
             }
         } else {
             col = sky_color(s, dir);
         }
-        if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
-        if (f.color8 || f.color8_strips) {
-            uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
-            if (f.color8) reinterpret_cast<uchar4*>(f.color8)[i] = c8;
-            if (f.color8_strips) reinterpret_cast<uchar4*>(f.color8_strips)[(size_t)(yp0 + (py - y0)) * (size_t)W + (size_t)px] = c8;
-        }
+        store_color(f, col, i, i32, ((uint32_t)(yp0 + (py - y0)) * (uint32_t)W + (uint32_t)px) << 2);
     } else if (hit) {
         // hit record for K2 (position bits + material | mask << 8 | (step+1) codes) and a slot in the compacted list of
         // hit pixels: K2 then runs one lane per HIT pixel instead of one per pixel (hipcc folds the per-lane
@@ -1006,13 +1055,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         P.hit_list[slot] = (uint32_t)i;
     } else {
         // misses are final here: colorMainRay is never reached (voxel_volume.frag:337-345)
-        f3 col = sky_color(s, dir);
-        if (f.color_f) { f.color_f[i * 3 + 0] = col.x; f.color_f[i * 3 + 1] = col.y; f.color_f[i * 3 + 2] = col.z; }
-        if (f.color8 || f.color8_strips) {
-            uchar4 c8; c8.x = unorm8(col.x); c8.y = unorm8(col.y); c8.z = unorm8(col.z); c8.w = 0;
-            if (f.color8) reinterpret_cast<uchar4*>(f.color8)[i] = c8;
-            if (f.color8_strips) reinterpret_cast<uchar4*>(f.color8_strips)[(size_t)(yp0 + (py - y0)) * (size_t)W + (size_t)px] = c8;
-        }
+        store_color(f, sky_color(s, dir), i, i32, ((uint32_t)(yp0 + (py - y0)) * (uint32_t)W + (uint32_t)px) << 2);
     }
 }
 
@@ -1083,8 +1126,9 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
     float cam[3], U[3];
     int shard_rank;
     uint32_t box;
-    SlotOf<TABLE>::head(P, frame, g, cam, U, shard_rank, box);
+    SlotOf<TABLE>::head(P, frame, g, U, shard_rank, box);
     if (box == 0xFF00FF00u) return;
+    { const f3 cp = SlotOf<TABLE>::cam_pos(P, frame); cam[0] = cp.x; cam[1] = cp.y; cam[2] = cp.z; }
     const uint32_t ci = blockIdx.x * 256u + threadIdx.x;
     if (ci >= P.n_cells) return;
     const uint32_t cell = P.cells[ci];

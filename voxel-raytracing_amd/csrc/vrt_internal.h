@@ -140,8 +140,9 @@ static_assert(sizeof(FrameSlot) == 256, "FrameSlot is sized for aligned scalar l
 
 // Everything a workgroup needs to find its tile, in one 64-byte block of the kernel arguments: a wave fetches it with one
 // scalar load and one wait instead of ten loads of one or two dwords, each waited for before the next could be issued.
+#define VRT_MAPFLAG_SKY_FAST 0x10000u   // TileMap::flags: GeomParams::sky_fast, where the wave finds it without a load of its own
 struct alignas(64) TileMap {
-    uint32_t flags;                    // vrt_settings.flags
+    uint32_t flags;                    // vrt_settings.flags (low 16 bits) | VRT_MAPFLAG_*
     int32_t  n_frames, xcd_turn;
     uint32_t wgs_per_frame, wgs_per_frame_rcp;
     int32_t  tiles_x;       uint32_t tiles_x_rcp;
