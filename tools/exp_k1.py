@@ -14,6 +14,7 @@ def flag(name, default):
 frames, reps = int(flag("--frames", "64")), int(flag("--reps", "40"))
 W, H = (int(x) for x in flag("--res", "1920x1080").split("x"))
 ab = flag("--ab", None)
+xflags = int(flag("--flags", "0"))         # extra vrt_settings.flags (8: 16x16-pixel workgroups of four waves)
 back = float(flag("--back", "0"))          # camera moved back along -z by this many voxels (far away: nearly every wave is a sky wave)
 turn = float(flag("--turn", "0"))          # degrees added to the yaw: 180 = every pixel is sky
 eng = vrt.Engine(0)
@@ -26,6 +27,11 @@ eng.set_timing(False)
 pushes = [vrt.make_push(vrt.CameraController(position=(pos0[0] + 1.5 * t, pos0[1] + 0.5 * t, pos0[2] + 2.0 * t - back), yaw=yaw + turn, pitch=pitch), (256, 256, 256), (W, H))
           for t in (8.0 * f / frames for f in range(frames))]
 st = vrt.VoxelRenderSettings.primary_only((W, H))
+if xflags:
+    _to_c = st.to_c
+    def to_c():
+        c = _to_c(); c.flags |= xflags; return c
+    st.to_c = to_c
 stage = vrt.GeometryStage(eng, st, sc)
 launch = stage.prepare_batch(frames) if frames > 1 else stage.prepare()
 def go():

@@ -254,7 +254,7 @@ class Engine:
 
     def set_option(self, name: str, value) -> None:
         """Development switch of this context (include/vrt.h vrt_ctx_set_option): speed only, never a result."""
-        check(lib().vrt_ctx_set_option(self.ctx, name.encode(), 1 if value else 0))
+        check(lib().vrt_ctx_set_option(self.ctx, name.encode(), int(value)))
 
     def option(self, name: str) -> int:
         v = C.c_int32()
