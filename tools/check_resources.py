@@ -17,13 +17,14 @@ CSRC = os.path.join(ROOT, "voxel-raytracing_amd", "csrc")
 
 # mangled-name fragment -> (what it is, max VGPRs, max SGPRs, max scratch bytes per lane)
 BUDGET = {
-    "k_primaryILi7ELb0ELi1ELb0EE": ("K1 primary-only, look-up loop, slots in the kernel arguments", 64, 80, 0),
-    "k_primaryILi7ELb0ELi1ELb1EE": ("K1 primary-only, look-up loop, slots in the table (the bench line's kernel)", 64, 80, 0),
-    "k_primaryILi7ELb0ELi4ELb0EE": ("megakernel without its bounce loop, kernel arguments", 64, 80, 0),
-    "k_primaryILi7ELb0ELi4ELb1EE": ("megakernel without its bounce loop, table", 72, 96, 0),
-    "k_primaryILi7ELb0ELi2ELb0EE": ("megakernel, kernel arguments (7 waves per SIMD by design)", 72, 96, 480),
-    "k_primaryILi7ELb0ELi2ELb1EE": ("megakernel, table", 72, 96, 480),
-    "k_primaryILi6ELb0ELi2ELb0EE": ("megakernel over bricks (config 5)", 80, 96, 480),
+    "k_primaryILi7ELb0ELi1ELb0ELi0EE": ("K1 primary-only, look-up loop, one frame per launch (rows dealt to the XCDs)", 64, 80, 0),
+    "k_primaryILi7ELb0ELi1ELb0ELi2EE": ("K1 primary-only, look-up loop, 8 frames in the kernel arguments (XCD regions)", 64, 80, 0),
+    "k_primaryILi7ELb0ELi1ELb1ELi2EE": ("K1 primary-only, look-up loop, slots in the table (the bench line's kernel)", 64, 80, 0),
+    "k_primaryILi7ELb0ELi4ELb0ELi0EE": ("megakernel without its bounce loop, one frame per launch", 64, 80, 0),
+    "k_primaryILi7ELb0ELi4ELb1ELi2EE": ("megakernel without its bounce loop, table", 72, 96, 0),
+    "k_primaryILi7ELb0ELi2ELb0ELi0EE": ("megakernel, one frame per launch (7 waves per SIMD by design)", 72, 96, 480),
+    "k_primaryILi7ELb0ELi2ELb1ELi2EE": ("megakernel, table", 72, 96, 480),
+    "k_primaryILi6ELb0ELi2ELb0ELi0EE": ("megakernel over bricks (config 5), one frame per launch", 80, 96, 480),
     "k_denoise_ldsILb0ELb0ELb0ELb1EE": ("K3 weighted pass, exact, packed", 128, 96, 0),
 }
 

@@ -42,7 +42,8 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 struct DevOptions {
     int tile_tags = 1;         // k_tile_tags ahead of K1
     int box_rect = 1;          // the frame's box rectangle
-    int xcd_regions = 1;       // launches of >= 8 unsharded frames: one screen region per XCD and frame
+    int xcd_regions = 0;       // launches of >= 8 unsharded frames: one screen region per XCD and frame (off: as a three-dimensional
+                               // grid the form runs 30 or 33.6 us per bench frame from one process to the next; rows dealt to the XCDs: 30.0)
     int fast_loop = 1;         // AUTO / DF through the hand-written look-up loop
     int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
@@ -135,7 +136,7 @@ int vrt_ctx_create(int device, vrt_ctx** out)
     c->device = device;
     for (const OptName& o : kOptNames) {                       // the one place the environment is read
         const char* e = getenv(o.env);
-        if (e && e[0] == '0') c->opt.*(o.field) = 0;
+        if (e && (e[0] == '0' || e[0] == '1')) c->opt.*(o.field) = e[0] - '0';
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(VRT_ERR_HIP, "hipStreamCreate failed"); }
     hipEventCreate(&c->ev_geo0); hipEventCreate(&c->ev_prim1); hipEventCreate(&c->ev_geo1);

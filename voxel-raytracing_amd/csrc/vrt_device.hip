@@ -791,34 +791,46 @@ template <> struct SlotOf<true> {
 //                  to XCD L % 8).  For row counts far from a multiple of 8 -- a rank's 18 rows of a sharded 1080p frame
 //                  would be 3 rows for two XCDs and 2 for the others, and a third of the grid would be surplus -- the XCDs
 //                  stay even and only the last seven row slots of the launch can be empty.
+// MAP: the launch's xcd_turn as a compile-time constant (the product traversals), or -1: looked at here
+template <int MAP>
 __device__ __forceinline__ bool block_to_tile(const TileMap& M, uint32_t& frame, int& ty, int& tx)
 {
-    uint32_t b = blockIdx.x, utx;
-    frame = 0;
-    if (M.xcd_turn == 2) {
-        // xcd_turn == 2: per frame every XCD owns ONE of 8 screen regions (2 columns x 4 rows of tiles), and the assignment
-        // rotates from frame to frame (XCD x traces region (x + frame) % 8): an XCD's rays of one frame then walk one
-        // eighth of the volume in one or two direction octants -- a working set of clearance bytes that fits its 4 MiB L2
-        // instead of the whole 17 MB field -- while over 8 frames every XCD traces every region once, so sky and geometry
-        // regions balance.  (wgs_per_frame = workgroup slots per region, tiles_y_rcp = floor(2^32 / region width).)
+    // xcd_turn 0 and 2 are launched as THREE-dimensional grids (8 x columns, rows, frames): the workgroup's three indices are in
+    // scalar registers when the wave starts, and the XCD (workgroups are dealt to the eight XCDs in dispatch order, x fastest)
+    // is the low three bits of the x index because the grid's x extent is a multiple of 8 -- no division, where the linear
+    // form spends two or three (ten scalar instructions each, in a kernel whose scalar unit -- ONE per CU, shared by its four
+    // SIMDs -- is as busy as its vector units: a 1080p frame of sky-only waves that return once they know their block takes
+    // 11 us, 158 scalar instructions per wave).
+    if (MAP == 2 || (MAP < 0 && M.xcd_turn == 2)) {
+        // per frame every XCD owns ONE of 8 screen regions (2 columns x 4 rows of tiles), and the assignment rotates from frame
+        // to frame (XCD x traces region (x + frame) % 8): an XCD's rays of one frame then walk one eighth of the volume in one
+        // or two direction octants -- a working set of clearance bytes that fits its 4 MiB L2 instead of the whole 17 MB field
+        // -- while over 8 frames every XCD traces every region once, so sky and geometry regions balance.
         const uint32_t rw = ((uint32_t)M.tiles_x + 1u) >> 1, rh = ((uint32_t)M.tiles_y_local + 3u) >> 2;
-        uint32_t within, uty;
-        frame = udiv_uniform(b >> 3, M.wgs_per_frame, M.wgs_per_frame_rcp, within);
-        uty = udiv_uniform(within, rw, M.tiles_y_rcp, utx);
-        const uint32_t region = ((b & 7u) + frame) & 7u;
-        tx = (int)(utx + (region & 1u) * rw);
-        ty = (int)(uty + (region >> 1) * rh);
-        return frame < (uint32_t)M.n_frames && uty < rh && tx < M.tiles_x && ty < M.tiles_y_local;
+        frame = blockIdx.z;
+        const uint32_t region = ((blockIdx.x & 7u) + frame) & 7u;
+        tx = (int)((blockIdx.x >> 3) + (region & 1u) * rw);
+        ty = (int)(blockIdx.y + (region >> 1) * rh);
+        return tx < M.tiles_x && ty < M.tiles_y_local;
     }
-    if (M.xcd_turn) {
-        uint32_t L = udiv_uniform(b >> 3, (uint32_t)M.tiles_x, M.tiles_x_rcp, utx) * 8u + (b & 7u), uty;
-        frame = udiv_uniform(L, (uint32_t)M.tiles_y_local, M.tiles_y_rcp, uty);
-        ty = (int)uty; tx = (int)utx;
-        return frame < (uint32_t)M.n_frames;
+    if (MAP == 0 || (MAP < 0 && M.xcd_turn == 0)) {
+        // per frame, row ty belongs to XCD ty % 8: every XCD gets an even sample of sky and geometry (a contiguous band per XCD
+        // leaves the XCDs that drew the sky idle), while the tiles of one row -- which walk neighbouring volume cells -- still
+        // share that XCD's L2; ceil(rows / 8) * 8 row slots per frame (the surplus workgroups exit at once)
+        frame = blockIdx.z;
+        tx = (int)(blockIdx.x >> 3);
+        ty = (int)(blockIdx.y * 8u + (blockIdx.x & 7u));
+        return ty < M.tiles_y_local;
     }
-    if (M.n_frames > 1) frame = udiv_uniform(blockIdx.x, M.wgs_per_frame, M.wgs_per_frame_rcp, b);
-    ty = (int)(udiv_uniform(b >> 3, (uint32_t)M.tiles_x, M.tiles_x_rcp, utx) * 8u + (b & 7u)); tx = (int)utx;
-    return ty < M.tiles_y_local;
+    // xcd_turn == 1 (a one-dimensional grid): the rows of ALL frames of the launch are dealt round-robin in one sequence (row
+    // L = frame * rows + ty to XCD L % 8).  For row counts far from a multiple of 8 -- a rank's 18 rows of a sharded 1080p
+    // frame would be 3 rows for two XCDs and 2 for the others, and a third of the grid would be surplus -- the XCDs stay even
+    // and only the last seven row slots of the launch can be empty.
+    uint32_t b = blockIdx.x, utx, uty;
+    uint32_t L = udiv_uniform(b >> 3, (uint32_t)M.tiles_x, M.tiles_x_rcp, utx) * 8u + (b & 7u);
+    frame = udiv_uniform(L, (uint32_t)M.tiles_y_local, M.tiles_y_rcp, uty);
+    ty = (int)uty; tx = (int)utx;
+    return frame < (uint32_t)M.n_frames;
 }
 
 // yp0: the row of y0 in the rank's packed strips (vrt_pack_rows order)
@@ -827,8 +839,9 @@ __device__ __forceinline__ bool tile_origin(const TileMap& M, int ty, int tx, in
     // bottom rows first: the rows dispatched last only have the drain of the machine to hide in, and the top of a
     // frame is where the cheap sky-only tiles usually are
     ty = M.tiles_y_local - 1 - ty;
-    uint32_t within;
-    int strip_local = (int)udiv_uniform((uint32_t)ty, M.tps, M.tps_rcp, within);
+    uint32_t within = (uint32_t)ty;
+    int strip_local = 0;                                       // (unsharded: the frame is one strip)
+    if (M.nranks > 1) strip_local = (int)udiv_uniform((uint32_t)ty, M.tps, M.tps_rcp, within);
     x0 = tx * M.tile;
     yp0 = strip_local * M.strip_rows + (int)within * M.tile;
     y0 = (strip_local * M.nranks + shard_rank) * M.strip_rows + (int)within * M.tile;
@@ -874,19 +887,16 @@ __device__ __forceinline__ void store_color(const vrt_frame& f, f3 col, size_t i
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
-template <int TRAV, bool OCC_LDS, int MODE, bool TABLE>
+template <int TRAV, bool OCC_LDS, int MODE, bool TABLE, int MAP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_primary(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     // the tile map arrives with one 64-byte scalar load (and one wait) before anything depends on it
     TileMap M = P.map;
-    asm volatile("" : "+s"(M.flags), "+s"(M.n_frames), "+s"(M.xcd_turn), "+s"(M.wgs_per_frame), "+s"(M.wgs_per_frame_rcp),
-                      "+s"(M.tiles_x), "+s"(M.tiles_x_rcp), "+s"(M.tiles_y_local), "+s"(M.tiles_y_rcp), "+s"(M.tps),
-                      "+s"(M.tps_rcp), "+s"(M.tile), "+s"(M.nranks), "+s"(M.strip_rows), "+s"(M.W), "+s"(M.H));
     const uint64_t t_begin = (M.flags & 2u) ? wall_clock64() : 0ull;         // diagnostic timeline (100 MHz)
     int x0, y0, yp0, ty, tx;
     uint32_t frame;
-    if (!block_to_tile(M, frame, ty, tx)) return;                        // uniform per workgroup
+    if (!block_to_tile<MAP>(M, frame, ty, tx)) return;                   // uniform per workgroup
     // the block's tile tag (k_tile_tags) and the frame's "the tags say nothing" word: two scalar loads that leave together with
     // the frame slot's (their address needs nothing from the slot: tags are laid out in the launch's LOCAL rows of 8x8 blocks,
     // in dispatch order), looked at after ray generation.  Written by the kernel before this one: constant address space.
@@ -1202,21 +1212,30 @@ hipError_t launch_tile_tags(const GeomParams& p, hipStream_t s)
 template <int TRAV, bool OCC_LDS>
 static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
 {
-    unsigned wgs = (unsigned)(p.chunk * 8) * (unsigned)p.n_frames;
-    if (p.xcd_turn == 2) wgs = 8u * (unsigned)p.n_frames * p.wgs_per_frame;
-    else if (p.xcd_turn) wgs = (unsigned)p.tiles_x * 8u * (unsigned)((p.tiles_y_local * p.n_frames + 7) / 8);
-    dim3 grid(wgs), block(p.tile_h == 8 ? 64 : 256);
+    // (block_to_tile: three-dimensional grids whose x extent is a multiple of 8 for xcd_turn 0 and 2, a line for xcd_turn 1)
+    dim3 grid((unsigned)p.tiles_x * 8u, (unsigned)((p.tiles_y_local + 7) / 8), (unsigned)p.n_frames);
+    if (p.xcd_turn == 2) grid = dim3(8u * (((unsigned)p.tiles_x + 1u) / 2u), ((unsigned)p.tiles_y_local + 3u) / 4u, (unsigned)p.n_frames);
+    else if (p.xcd_turn) grid = dim3((unsigned)p.tiles_x * 8u * (unsigned)((p.tiles_y_local * p.n_frames + 7) / 8));
+    dim3 block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
+    // (the product traversals with the tile map's form as a compile-time constant: block_to_tile)
+    constexpr bool kProduct = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_BRICK;
+    const int map = (kProduct && p.xcd_turn != 1) ? p.xcd_turn : -1;
+#define VRT_LAUNCH_K1(MODE_, TABLE_)                                                                                           \
+    do {                                                                                                                       \
+        if (kProduct && map == 0)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, kProduct ? 0 : -1>), grid, block, lds, s, p); \
+        else if (kProduct && map == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, kProduct ? 2 : -1>), grid, block, lds, s, p); \
+        else                           hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, -1>), grid, block, lds, s, p);    \
+    } while (0)
     if (p.table) {               // the split form renders one frame per launch and never gets here
-        if (p.fused_shade == 1)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, true>), grid, block, lds, s, p);
-        else if (p.fused_shade == 2) { if (p.no_bounce) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 4, true>), grid, block, lds, s, p);
-                                       else             hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, true>), grid, block, lds, s, p); }
+        if (p.fused_shade == 1)      VRT_LAUNCH_K1(1, true);
+        else if (p.fused_shade == 2) { if (p.no_bounce) VRT_LAUNCH_K1(4, true); else VRT_LAUNCH_K1(2, true); }
         else return hipErrorInvalidValue;
     }
-    else if (p.fused_shade == 1) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 1, false>), grid, block, lds, s, p);
-    else if (p.fused_shade == 2) { if (p.no_bounce) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 4, false>), grid, block, lds, s, p);
-                                   else             hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 2, false>), grid, block, lds, s, p); }
-    else                         hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, 0, false>), grid, block, lds, s, p);
+    else if (p.fused_shade == 1) VRT_LAUNCH_K1(1, false);
+    else if (p.fused_shade == 2) { if (p.no_bounce) VRT_LAUNCH_K1(4, false); else VRT_LAUNCH_K1(2, false); }
+    else                         VRT_LAUNCH_K1(0, false);
+#undef VRT_LAUNCH_K1
     return hipGetLastError();
 }
 
