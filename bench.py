@@ -20,6 +20,13 @@ collective and no copy.
 Workload = BASELINE.json configs[1]: treehouse stand-in (synthetic:treehouse(seed=2), 256^3 -- the real
 treehouse.vox is a git-LFS pointer in the reference checkout), 1920x1080, primary rays only.
 
+roofline.frac is computed over the work the kernel PERFORMS: 1 B per DDA iteration the product march really takes (summed over
+every frame of the launch, from the march's own counters) + 37 B per pixel, over the kernel's measured duration.  The same
+formula over the iterations of the REFERENCE's loop (SURVEY 8(d)'s count; rays end early at open cells and untagged blocks are
+not traced, so the product takes fewer) is kept as roofline.frac_reference_steps -- it passes 1 and is not a bound.
+roofline.hbm_frac is the PMC traffic (profiles/*_k_primary_pmc.json, quoted only while its csrc digest matches) over the same
+time and peak; roofline.write_floor_ms the stored bytes at the 6.1 TB/s plain stores reach on this part.
+
 Besides the headline the JSON line carries (rank 0, N = 1, outside the timed region):
   roofline.single_frame_launch   the same kernel with ONE frame per launch (the reference's call pattern, engine.cpp:81-92)
   extra_configs                  BASELINE configs[2] (shadow ray + 1 and 2 denoiser passes) and the reference's default
@@ -38,6 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured-achievable
+STORE_GBS = 6100.0             # what plain stores reach on this part (same guide): the floor of a kernel that only writes its G-buffer
 B_OUT = 37                     # bytes stored per pixel: the reference's 6-target G-buffer (geometry_stage.cpp:22-33)
 K3_BYTES_PASS0 = 8             # denoiser pass 0 (phi = +inf): colour in + colour out
 K3_BYTES_PASS = 28             # weighted pass: colour + normal + position in (4 + 4 + 16), colour out
@@ -84,6 +92,7 @@ def spawn_ranks(n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import threading
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -91,6 +100,15 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained WHILE the ranks run (a reader thread): a pipe holds about 64 KiB, and a rank 0 that wrote more
+    # would block on write while this process waits for it to exit
+    chunks = []
+
+    def drain():
+        for line in iter(procs[0].stdout.readline, b""):
+            chunks.append(line)
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
     rc = 0
     live = set(range(n))
     while live and rc == 0:
@@ -111,10 +129,13 @@ def spawn_ranks(n):
             procs[r].wait(timeout=10)
         except Exception:
             procs[r].kill()
-    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    reader.join(timeout=10)
+    out = b"".join(chunks).decode(errors="replace")
     if rc == 0:
         sys.stdout.write(out)
         sys.stdout.flush()
+    elif out:                                                  # a failed run: what rank 0 said goes to stderr, never lost
+        log("bench.py: rank 0 wrote before the failure:\n" + out)
     return rc
 
 
@@ -145,7 +166,22 @@ def median(xs):
     return xs[len(xs) // 2]
 
 
-def single_frame_launch(vrt, engine, renderer, pushes, W, H, S_frames, reps=3):
+def marched_counts(vrt, torch, engine, scene, st, push, W, H):
+    """(DDA iterations of the primary rays, of all rays, rays traced) as the PRODUCT march performs them for one frame:
+    VRT_FLAG_MARCHED_COUNTS makes the count planes report the march's own work -- rays end at open cells, untagged blocks are not
+    traced, an any-hit ray decided at a look-up reports the iterations it took -- where they otherwise hold the REFERENCE loop's."""
+    import ctypes as C
+    gbm = vrt.GeometryBuffer(engine, W, H, ("steps_primary", "steps_total", "rays_total"))
+    stc = st.to_c(); stc.flags |= 16
+    frm = gbm.to_c()
+    vrt._capi.check(vrt.lib().vrt_render_geometry(engine.ctx, scene.handle, C.byref(push), C.byref(stc), C.byref(frm), None))
+    engine.synchronize()
+    out = tuple(int(getattr(gbm, n).to(torch.int64).sum().item()) for n in ("steps_primary", "steps_total", "rays_total"))
+    del gbm
+    return out
+
+
+def single_frame_launch(vrt, engine, renderer, pushes, W, H, S_frames, M_frames=None, reps=3):
     """K1 with ONE frame per launch: every launch alone on the device (synchronised before the next), timed by the
     library's HIP events around the kernel; mean over the step's poses, best of `reps` sweeps."""
     stage = renderer._geometryStage
@@ -161,8 +197,10 @@ def single_frame_launch(vrt, engine, renderer, pushes, W, H, S_frames, reps=3):
         best = tot if best is None or tot < best else best
     engine.set_timing(False)
     ms = best / len(pushes)
-    b_alg = (sum(S_frames) / len(S_frames)) + W * H * B_OUT
-    return {"kernel_ms": round(ms, 5), "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+    b_ref = (sum(S_frames) / len(S_frames)) + W * H * B_OUT
+    b_alg = ((sum(M_frames) / len(M_frames)) if M_frames else 0) + W * H * B_OUT
+    return {"kernel_ms": round(ms, 5), "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if M_frames else None,
+            "frac_reference_steps": round(b_ref / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "Mrays_per_s": round(W * H / (ms * 1e-3) / 1e6, 1),
             "sample": f"{len(pushes)} poses of the step, one vrt_render_geometry call each, device idle between launches"}
 
@@ -197,11 +235,15 @@ def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounc
     rays = int(dbg.rays_total.to(torch.int64).sum().item())
     engine.set_timing(False)
     g_ms = median(tg)
-    b_geo = S + W * H * B_OUT
+    _, S_marched, _ = marched_counts(vrt, torch, engine, scene, st, push, W, H)
+    b_ref = S + W * H * B_OUT                                  # the reference loop's iterations (SURVEY 8(d)'s count)
+    b_geo = S_marched + W * H * B_OUT                          # the iterations the product march takes
     out = {"name": name, "ao_samples": ao, "shadows": int(bool(shadows)), "max_bounces": bounces, "denoiser_passes": iters,
            "resolution": [W, H], "max_steps": max_steps, "geometry_kernel": kernel, "geometry_ms": round(g_ms, 5),
-           "rays_total": rays, "dda_steps_total": S, "Mrays_total_per_s": round(rays / (g_ms * 1e-3) / 1e6, 1),
-           "geometry_algorithmic_bytes": b_geo, "geometry_frac": round(b_geo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+           "rays_total": rays, "dda_steps_total": S, "dda_steps_marched": S_marched, "Mrays_total_per_s": round(rays / (g_ms * 1e-3) / 1e6, 1),
+           "geometry_algorithmic_bytes": b_geo, "geometry_frac": round(b_geo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+           "geometry_frac_reference_steps": round(b_ref / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+           "write_floor_ms": round(W * H * B_OUT / (STORE_GBS * 1e9) * 1e3, 5)}
     if batch_pushes:
         # the same settings with several frames per launch (consecutive poses): a hit wave's chain of secondary traces then has
         # other frames' waves to hide behind, as the headline's primary rays have
@@ -225,6 +267,52 @@ def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounc
                     "denoise_frac": round(b_den / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "frame_ms": round(g_ms + d_ms, 5)})
     return out
+
+
+def primary_4k(vrt, torch, engine, scene, NV, pos0, yaw, pitch, W=3840, H=2160, nb=16):
+    """The headline's workload at 3840x2160: K1 batched (nb frames per launch) and one frame per launch."""
+    import numpy as np
+    st = vrt.VoxelRenderSettings.primary_only((W, H))
+    pushes = [vrt.make_push(vrt.CameraController(position=(pos0[0] + 1.5 * t, pos0[1] + 0.5 * t, pos0[2] + 2.0 * t), yaw=yaw, pitch=pitch), (NV, NV, NV), (W, H))
+              for t in (8.0 * f / nb for f in range(nb))]
+    stage = vrt.GeometryStage(engine, st, scene)
+    launch = stage.prepare_batch(nb)
+    for _ in range(3):
+        launch(pushes)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        launch(pushes)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10 / nb
+    del launch
+    single = stage.prepare()
+    engine.set_timing(True)
+    t1 = []
+    for p in pushes:
+        single(p); engine.synchronize()
+        t1.append(engine.last_timings()["primary_ms"])
+    engine.set_timing(False)
+    dbg = vrt.GeometryStage(engine, vrt.VoxelRenderSettings.primary_only((W, H), vrt.TRAVERSAL_BITMASK), scene, debug_planes=True)
+    S, M = [], []
+    for p in pushes[::4]:
+        gb = dbg.record(p); engine.synchronize()
+        S.append(int(gb.steps_primary.to(torch.int64).sum().item()))
+        M.append(marched_counts(vrt, torch, engine, scene, st, p, W, H)[0])
+    del dbg, gb
+    px = W * H * B_OUT
+    b_alg, b_ref = sum(M) / len(M) + px, sum(S) / len(S) + px
+    ms1 = sum(t1) / len(t1)
+    return {"name": f"configs[1] at 4K: primary rays only, {W}x{H}, the headline's scene and camera path", "resolution": [W, H],
+            "geometry_kernel": "k_tile_tags + k_primary<DF, primary only>", "batched_frames_per_launch": nb,
+            "geometry_ms_per_frame_batched": round(ms, 5), "Mrays_per_s_batched": round(W * H / (ms * 1e-3) / 1e6, 1),
+            "geometry_frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "geometry_frac_reference_steps": round(b_ref / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "geometry_ms": round(ms1, 5), "Mrays_per_s_single_frame": round(W * H / (ms1 * 1e-3) / 1e6, 1),
+            "single_frame_frac": round(b_alg / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "dda_steps_per_frame": int(sum(S) / len(S)), "dda_steps_marched_per_frame": int(sum(M) / len(M)),
+            "write_floor_ms": round(px / (STORE_GBS * 1e9) * 1e3, 5)}
 
 
 def main():
@@ -342,37 +430,37 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- algorithmic bytes of one K1 launch: S fetches (1 B each) + W*H*B_out ----
+        # ---- algorithmic bytes of one K1 launch (1 B per DDA iteration + W*H*B_out) ----
+        # S_frames: the iterations of the REFERENCE's loop (every ray walks to a hit, the wall or the end of its budget);
+        # M_frames: the iterations the product march really takes (rays end at open cells, untagged blocks are not traced) --
+        # every frame of the launch, not one extrapolated
         engine.set_timing(True)
         st_dbg = vrt.VoxelRenderSettings.primary_only((W, H), vrt.TRAVERSAL_BITMASK)
         stage = vrt.GeometryStage(engine, st_dbg, scene, debug_planes=True)
-        S_frames, hit_frac = [], []
+        S_frames, M_frames, hit_frac = [], [], []
         frames_per_launch = min(F, 256)
         for f in range(frames_per_launch):                    # the frames of the first launch of a step
             gb = stage.record(pushes[f])
             engine.synchronize()
             S_frames.append(int(gb.steps_primary.to(torch.int64).sum().item()))
             hit_frac.append(float((gb.hit_id != 0).float().mean().item()))
-            if f == 0:
-                hit0 = gb.hit_id.cpu().numpy()
+            M_frames.append(marched_counts(vrt, torch, engine, scene, st, pushes[f], W, H)[0])
         del stage, gb
         S_frame = S_frames[0]
-        # ... and the iterations the product march really takes for frame 0 (the product kernel's own development counters):
-        # rays end at open cells, blocks without a tile tag are not traced -- S above is the REFERENCE loop's count
-        marched = None
-        try:
-            import ctypes as C
-            gbm = vrt.GeometryBuffer(engine, W, H, ("steps_primary",))
-            stc = st.to_c(); stc.flags = 1
-            frm = gbm.to_c()
-            vrt._capi.check(vrt.lib().vrt_render_geometry(engine.ctx, scene.handle, C.byref(pushes[0]), C.byref(stc), C.byref(frm), None))
-            engine.synchronize()
-            marched = int(gbm.steps_primary.to(torch.int64).sum().item())
-            del gbm
-        except Exception as e:                                 # (a diagnostic: never fails the bench line)
-            log(f"bench.py: marched-steps diagnostic skipped: {e}")
+        # frame 0's hit ids as the TIMED configuration produces them (AUTO: the hand-written loop, open cells, tile tags, the sky
+        # fast path), for the CPU leg's comparison
+        import ctypes as C
+        gbh = vrt.GeometryBuffer(engine, W, H, ("hit_id", "color8"))
+        stc, frm = st.to_c(), gbh.to_c()
+        vrt._capi.check(vrt.lib().vrt_render_geometry(engine.ctx, scene.handle, C.byref(pushes[0]), C.byref(stc), C.byref(frm), None))
+        engine.synchronize()
+        hit0 = gbh.hit_id.cpu().numpy()
+        color0 = gbh.color8.cpu().numpy()
+        del gbh
         # a launch covers this rank's strips (1 / world of the rows) of frames_per_launch frames
-        b_alg = (sum(S_frames) + frames_per_launch * W * H * B_OUT) / world
+        px_bytes = frames_per_launch * W * H * B_OUT / world
+        b_alg = sum(M_frames) / world + px_bytes
+        b_ref = sum(S_frames) / world + px_bytes
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         tm = engine.last_timings()
         # HBM bytes per K1 launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
@@ -396,23 +484,46 @@ def main():
                 traffic, traffic_src = None, f"dropped: {e}"
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "frac_is": "algorithmic bytes (SURVEY 8(d): 1 B per DDA step of the REFERENCE's loop + 37 B per pixel) / kernel time / peak; "
-                               "the product does not take every one of those steps (open cells, tile tags: DESIGN.md 5), so the figure can pass 1 -- "
-                               "frac_marched counts the iterations actually marched instead",
+                    "frac_is": "bytes of the work PERFORMED (1 B per DDA iteration the product march takes, summed over the launch's frames, "
+                               "+ 37 B per pixel) / kernel time / peak",
+                    "hbm_frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                     "traffic_GBps": round(traffic / (kern_ms * 1e-3) / 1e9, 2) if traffic else None,
+                    "write_floor_ms": round(px_bytes / (STORE_GBS * 1e9) * 1e3, 5),
+                    "frac_reference_steps": round(b_ref / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "frac_reference_steps_is": "the same formula over the iterations of the REFERENCE's loop (SURVEY 8(d)'s count): the product proves most "
+                                               "of them unnecessary (open cells, tile tags: DESIGN.md 5) and does not take them, so this figure passes 1 -- not a bound",
                     "kernel": "k_tile_tags + k_primary (one launch of each per step)", "kernel_ms": round(kern_ms, 5), "csrc_sha16": csrc_sha16(),
                     "frames_per_launch": frames_per_launch, "algorithmic_bytes_per_launch": int(b_alg),
+                    "dda_steps_marched_per_launch": int(sum(M_frames)), "dda_steps_reference_per_launch": int(sum(S_frames)),
                     "dda_steps_per_frame": S_frame, "steps_per_ray": round(S_frame / (W * H), 2),
-                    "dda_steps_marched_frame0": marched,
-                    "frac_marched": (round((marched + W * H * B_OUT) * frames_per_launch / world / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                                     if marched is not None else None)}
+                    "dda_steps_marched_frame0": M_frames[0]}
         extra = None
         if world == 1 and not args.no_extra_configs:
-            roofline["single_frame_launch"] = single_frame_launch(vrt, engine, renderer, pushes[:frames_per_launch], W, H, S_frames)
+            roofline["single_frame_launch"] = single_frame_launch(vrt, engine, renderer, pushes[:frames_per_launch], W, H, S_frames, M_frames)
             extra = [extra_config(vrt, torch, engine, scene, pushes[0], W, H, *c, batch_pushes=pushes[:16]) for c in (
                 ("configs[2]: primary + shadow ray, 1 denoiser pass", 0, True, 0, 1),
                 ("configs[2]: primary + shadow ray, 2 denoiser passes", 0, True, 0, 2),
                 ("reference defaults: AO 4 x 64 steps, shadow ray, <= 5 bounces, 2 denoiser passes", 4, True, 5, 2))]
+            # north_star's "1080p and 4K": the headline's scene and camera path at 3840x2160, primary rays only -- batched like the
+            # headline (16 frames per launch: 77 MB of planes x 4 each) and one frame per launch
+            extra.append(primary_4k(vrt, torch, engine, scene, NV, pos0, yaw, pitch))
+            # BASELINE configs[3]: Mandelbulb 512^3 at 3840x2160, 2 bounces, AO 4 + shadow ray (one GPU's view of the frame the
+            # 8-GPU run cuts into strips)
+            t_gen = time.perf_counter()
+            volm = vrt.synthetic.mandelbulb(512)
+            scm = vrt.VoxelScene.from_dense(engine, volm, pal, sky=sky, noise=noise)
+            camm = vrt.CameraController(position=(512 * 0.5 + 0.3, 512 * 0.5 + 0.2, -0.45 * 512))
+            pushm = vrt.make_push(camm, (512, 512, 512), (3840, 2160), frame=5)
+            batchm = [vrt.make_push(vrt.CameraController(position=(512 * 0.5 + 0.3 + 1.5 * k, 512 * 0.5 + 0.2 + 0.5 * k, -0.45 * 512 + 2.0 * k)),
+                                    (512, 512, 512), (3840, 2160), frame=5 + k) for k in range(4)]
+            em = extra_config(vrt, torch, engine, scm, pushm, 3840, 2160,
+                              "configs[3]: synthetic:mandelbulb(N=512), 3840x2160, 2 bounces, AO 4 x 64 steps, shadow ray", 4, True, 2, 0,
+                              reps=5, kernel="k_primary<DF, megakernel>", batch_pushes=batchm)
+            em["scene_device_bytes"] = scm.memory_bytes()
+            em["scene_build_s"] = round(time.perf_counter() - t_gen, 2)
+            extra.append(em)
+            scm.destroy()
+            del volm
             # BASELINE configs[4]: the 2048^3 brick scene at 3840x2160 (one GPU's view of it; the 8-GPU split is the same frame
             # cut into strips) -- the one configuration whose volume does not sit in the caches
             t_gen = time.perf_counter()
@@ -439,16 +550,18 @@ def main():
             # camera path (about 10 CPU-seconds at 1080p: 0.6 s of wall time on 16 threads)
             sample = list(range(0, F, max(1, F // 8)))[:8]
             c0 = time.perf_counter()
-            same = True
+            same, same_color = True, True
             for f in sample:
-                exp = oracle.render(osn, pushes[f], oracle.params_from(st.to_c()), planes=["hit_id", "steps_primary"], nthreads=ncores)
-                if f == 0:
+                exp = oracle.render(osn, pushes[f], oracle.params_from(st.to_c()), planes=["hit_id", "steps_primary", "color8"], nthreads=ncores)
+                if f == 0:                                     # the oracle's frame against what the TIMED kernel configuration renders
                     same = bool((exp["hit_id"] == hit0).all()) and int(exp["steps_primary"].sum()) == S_frame
+                    same_color = bool((exp["color8"] == color0).all())
             cdt = time.perf_counter() - c0
             cpu = {"value": round(len(sample) * W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
                    "sample": f"{len(sample)} full {W}x{H} frames of the same workload (every {max(1, F // 8)}th pose of the step), scalar C oracle, "
                              f"rows interleaved over {ncores} threads, {cdt:.2f} s",
-                   "hit_ids_match_gpu": same}
+                   "hit_ids_match_gpu": same, "color8_matches_gpu": same_color,
+                   "compared_with": "frame 0 as the timed configuration renders it (AUTO: hand-written loop, open cells, tile tags, sky fast path)"}
             # one thread on a band of the same frame (every 8th row group would bias towards sky; a centred band does not)
             r0, r1 = H // 2 - 60, H // 2 + 60
             c1 = time.perf_counter()

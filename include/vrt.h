@@ -72,6 +72,10 @@ typedef struct vrt_push {
 
 #define VRT_FLAG_SPLIT_KERNELS 4u /* trace secondary rays in a second kernel (K2) over the compacted hit list instead of inside K1 */
 #define VRT_FLAG_DEBUG_PLANES 1u  /* steps_total / rays_total receive traversal diagnostics instead (development aid) */
+#define VRT_FLAG_MARCHED_COUNTS 16u /* the count planes (steps_primary, steps_total, rays_total) report the PRODUCT march's own work -- rays
+                                     * end at open cells, untagged blocks are not traced, an any-hit ray decided at a look-up reports the
+                                     * iterations it took -- instead of the reference loop's iterations; every other plane is unchanged.
+                                     * bench.py's roofline figures count these */
 
 /* VolumeParameters (parameters.hpp:5-9) + Light (voxel_scene.hpp:10-15) as GeometryStage::record fills
  * them each frame (geometry_stage.cpp:135-145), plus the shader's compile-time constants

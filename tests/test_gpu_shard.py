@@ -345,3 +345,30 @@ def test_sharded_batch_with_denoiser(vrt, engine, mode, rotate, iters, step_widt
             for j, f in enumerate(sb.owned_frames()):
                 assert (finals[j] == ref[f]).all(), (d, f, int((finals[j] != ref[f]).sum()))
     assert (ref[0] != ref[1]).any()
+
+
+def test_batch_of_one_rank_honours_denoise_and_refuses_what_it_cannot_do(vrt, oracle, engine):
+    """ShardedBatch(denoise=True) at N = 1 returns the filtered colour of every frame, as it does at N > 1 (it used to hand back
+    the raw G-buffers); with the denoiser switched off in the settings, or with a diagnostic-plane stage in direct mode, it says
+    so instead of dropping the request."""
+    D = vrt.distributed
+    vol = vrt.synthetic.floating_cubes(32, seed=3, count=20)
+    pal = vrt.synthetic.default_palette(metallic_ids=range(200, 256))
+    sc = vrt.VoxelScene.from_dense(engine, vol, pal, sky=vrt.synthetic.sky_gradient(32, 16), noise=vrt.synthetic.blue_noise_standin(32))
+    res = (96, 64)
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    st.traceSettings.shadows = True
+    st.denoiserSettings.enable = True
+    pushes = [vrt.make_push(vrt.CameraController(position=(16.0 + f, 17.0, -30.0)), (32, 32, 32), res, frame=f) for f in range(3)]
+    got = D.ShardedBatch(vrt.GeometryStage(engine, st, sc), 3, 0, 1, denoise=True).step(pushes)
+    engine.synchronize()
+    osn = oracle.OracleScene(vol, pal, sky=vrt.synthetic.sky_gradient(32, 16), noise=vrt.synthetic.blue_noise_standin(32))
+    for f in range(3):
+        exp = oracle.render(osn, pushes[f], oracle.params_from(st.to_c()), planes=["color8", "normal8", "position"], nthreads=4)
+        assert (got[f].cpu().numpy() == oracle.denoise(exp["color8"], exp["normal8"], exp["position"])).all(), f
+    st.denoiserSettings.enable = False
+    with pytest.raises(ValueError):
+        D.ShardedBatch(vrt.GeometryStage(engine, st, sc), 3, 0, 1, denoise=True)
+    with pytest.raises(ValueError):
+        D.ShardedBatch(vrt.GeometryStage(engine, st, sc, debug_planes=True), 4, 0, 2, direct=True)
+    sc.destroy()

@@ -873,7 +873,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     // a launch that writes count planes reports the iterations of the reference's loop: it marches through the fields without
     // open cells (with the development flags the planes hold the product march's own counters instead)
     bool counts = false;
-    if (!(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)))
+    p.sc.vol.count_marched = (st->flags & VRT_FLAG_MARCHED_COUNTS) ? 1u : 0u;
+    if (!(st->flags & (VRT_FLAG_DEBUG_PLANES | VRT_FLAG_MARCHED_COUNTS | 2u)))
         for (int f = 0; f < n && !counts; f++) counts = frames[f].steps_primary != nullptr || frames[f].steps_total != nullptr;
     if (s->bricks && counts) p.sc.vol.brick_open = 0u;
     if (!s->bricks && s->open_cells) {
@@ -1348,9 +1349,8 @@ struct Rccl {
 Rccl* rccl()
 {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;                                // (contexts on several threads may ask at once)
+    std::call_once(once, [] {
         for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
@@ -1365,7 +1365,7 @@ Rccl* rccl()
                 dlclose(r.lib); r.lib = nullptr;
             }
         }
-    }
+    });
     return r.lib ? &r : nullptr;
 }
 

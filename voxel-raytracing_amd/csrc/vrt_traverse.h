@@ -59,7 +59,9 @@ struct VolumeView {
     uint32_t        df_fast;    // 1: the allocation continues with a ninth field, the voxel ids in the same zero-bordered layout
                                 // (field 8), and one byte 0xFF at offset 9 * df_stride, and all of it is addressable with
                                 // 32-bit offsets (trace_df_fast)
-    uint32_t        df_pad_;
+    uint32_t        count_marched; // 1 (VRT_FLAG_MARCHED_COUNTS): an any-hit ray that is decided a miss without stepping (its clearance covers
+                                // what is left of its budget) reports the iterations it TOOK, not the budget the reference's loop would
+                                // have spent -- the count planes then hold the product march's own work
     // brick scenes (vrt_scene_from_bricks; vox / occ* / df are null): the volume in 8^3 bricks.  All grids are padded by one
     // brick on every side (index (bx+1) + ((by+1) + (bz+1) * pby) * pbx), the border counting as outside the volume.
     const uint32_t* bgrid;      // 0 = empty brick, 0xFFFFFFFF = border (outside the volume), else 1 + index into bpool / bfine
@@ -901,7 +903,9 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
         "s_and_b64 vcc, vcc, s[64:65]\n\t"
         "s_cbranch_vccz 111f\n\t"
         "s_and_saveexec_b64 s[66:67], vcc\n\t"
-        "v_mov_b32 %[fet], %[maxs]\n\t"
+        "s_cmp_eq_u32 %[any], 2\n\t"                              // (any == 2: report the iterations taken, VolumeView::count_marched)
+        "s_cselect_b32 s62, s60, %[maxs]\n\t"
+        "v_mov_b32 %[fet], s62\n\t"
         "v_mov_b32 %[dx], 0\n\t"
         "v_mov_b32 %[dy], 0\n\t"
         "v_mov_b32 %[dz], 0\n\t"
@@ -1155,7 +1159,7 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
 __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
                                             float& x, float& y, float& z, float dx, float dy, float dz,
                                             float gx, float gy, float gz, float cx, float cy, float cz,
-                                            uint32_t idx0, uint32_t voxoff, uint32_t& material, uint32_t& fetches)
+                                            uint32_t idx0, uint32_t voxoff, uint32_t& material, uint32_t& fetches, uint32_t marched)
 {
     // vectors of the block: v48..v50 temporaries, v52 the byte read, v53 its index, v54 = i (iterations this lane has taken),
     // v55 = iterations this lane may still take before it has to look again; scalars: s63 = 0xFF, s[64:65] lanes with some left,
@@ -1215,6 +1219,10 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
         "s_cbranch_vccz 13f\n\t"
         "s_and_saveexec_b64 s[66:67], vcc\n\t"
         "v_mov_b32 %[fet], %[maxs]\n\t"
+        "s_cmp_eq_u32 %[mar], 0\n\t"                            // (VolumeView::count_marched: the iterations this lane took)
+        "s_cbranch_scc1 131f\n\t"
+        "v_mov_b32 %[fet], v54\n\t"
+        "131:\n\t"
         VRT_A_FINISH
         "s_mov_b64 exec, s[66:67]\n\t"
         "13:\n\t"
@@ -1247,7 +1255,7 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
         : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
           [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
           [idx0] "+v"(idx0), [mat] "+v"(material), [fet] "+v"(fetches)
-        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
+        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [mar] "s"(marched)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55",
           "s63", "s64", "s65", "s66", "s67", "s68", "s69");
 #undef VRT_A_FINISH
@@ -1292,11 +1300,12 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));      // (the builtin returns int)
     if (ANYHIT && OWN && __builtin_amdgcn_readfirstlane((int)v.df_own) != 0) {
         df_any_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, material, fetches);
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, material, fetches,
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)v.count_marched));
     } else
     df_fast_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
-                 incx, incy, incz, ANYHIT ? 1u : 0u, PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v.df_prefetch) : 0u);
+                 incx, incy, incz, ANYHIT ? 1u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(v.count_marched != 0u)) : 0u, PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v.df_prefetch) : 0u);
     s.sdx = x; s.sdy = y; s.sdz = z;
     finish(s, material, lmask, fetches + (material != 0u ? 1u : 0u), r);
     (void)stats;
@@ -1392,7 +1401,7 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
 #endif
                 } else if (ANYHIT && clear >= maxSteps - i) {
                     // any-hit ray whose clearance covers the rest of its budget: a miss with fetches = maxSteps, no stepping
-                    done = true; fetches = maxSteps;
+                    done = true; fetches = v.count_marched ? i : maxSteps;
                 }
             }
         }
@@ -1468,7 +1477,7 @@ __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f
                     if (oob(v, s.mx, s.my, s.mz)) fetches = i;
                     else { material = m; fetches = i + 1u; }
                     done = true;
-                } else if (clear >= maxSteps - i) { done = true; fetches = maxSteps; }
+                } else if (clear >= maxSteps - i) { done = true; fetches = v.count_marched ? i : maxSteps; }
                 else own = clear < (uint32_t)VRT_OWN_CAP_BRICK ? clear : (uint32_t)VRT_OWN_CAP_BRICK;
             }
         }

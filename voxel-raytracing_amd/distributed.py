@@ -246,7 +246,14 @@ class ShardedBatch:
     def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False,
                  assemble_on: str = "root", rotate: bool = None, direct: bool = True, side_unpack: bool = False, denoise: bool = False):
         import torch
-        self.denoise = bool(denoise) and bool(stage._settings.denoiserSettings.enable) and int(nranks) > 1
+        if denoise and not stage._settings.denoiserSettings.enable:
+            raise ValueError("ShardedBatch(denoise=True) with the denoiser switched off in the stage's settings (denoiserSettings.enable)")
+        if direct and int(nranks) > 1 and getattr(stage, "_debug", False):
+            raise ValueError("ShardedBatch(direct=...) launches write the frames' planes through its own frame table, which carries no "
+                             "diagnostic planes (hit_voxel, steps_*): use direct=False with a debug_planes stage")
+        # N = 1: the same call returns filtered frames as at N > 1 -- the unsharded denoiser on every frame of the batch (step())
+        self._denoise_alone = bool(denoise) and int(nranks) <= 1
+        self.denoise = bool(denoise) and int(nranks) > 1
         if self.denoise:
             direct = False                                     # the colour that travels is the denoiser's output, not K1's
         self.stage, self.F = stage, int(n_frames)
@@ -542,6 +549,11 @@ class ShardedBatch:
         N = 1: this step's GeometryBuffers."""
         gbs = self.render(pushes)
         if self.nranks <= 1:
+            if self._denoise_alone:                            # what N > 1 returns with denoise=True: the filtered colour of every frame
+                from .host import DenoiserStage
+                if not hasattr(self, "_alone"):
+                    self._alone = [DenoiserStage(self.stage.engine, self.stage._settings) for _ in gbs]
+                return [d.record(g.color, g.normal, g.position) for d, g in zip(self._alone, gbs)]
             return gbs
         if getattr(self, "denoise", False):
             self.denoise_step()
