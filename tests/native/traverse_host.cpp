@@ -105,6 +105,7 @@ struct HostBricks {
     VolumeView v;
     std::vector<uint32_t> grid;
     std::vector<uint8_t> coarse, pool, fine;
+    std::vector<uint64_t> entry;
 };
 
 // clearance of every cell of a W x H x D occupancy (outside = solid) towards octant o, capped: three one-sided min-max passes
@@ -171,6 +172,13 @@ void* thb_create(const uint8_t* vox, int W, int H, int D)                // dime
             h->coarse[(size_t)o * cstride + (size_t)(bx + 1) + ((size_t)(by + 1) + (size_t)(bz + 1) * pby) * pbx] = c[(size_t)bx + ((size_t)by + (size_t)bz * nby) * nbx];
     }
     if (h->pool.empty()) { h->pool.push_back(0); h->fine.push_back(0); }
+    h->entry.resize(cstride);
+    for (size_t i = 0; i < cstride; i++) {
+        uint8_t c8[8];
+        for (int o = 0; o < 8; o++) c8[o] = h->coarse[(size_t)o * cstride + i];
+        h->entry[i] = brick_entry_pack(h->grid[i], c8);
+    }
+    v.bentry = h->entry.data();
     v.bgrid = h->grid.data(); v.bcoarse = h->coarse.data(); v.bcoarse_stride = cstride; v.bpool = h->pool.data(); v.bfine = h->fine.data();
     return h;
 }

@@ -114,6 +114,7 @@ struct vrt_scene {
     uint32_t occ2_bytes = 0, occ3_bytes = 0;
     // brick scenes
     uint32_t* bgrid = nullptr; uint8_t* bcoarse = nullptr; uint8_t* bpool = nullptr; uint8_t* bfine = nullptr;
+    uint64_t* bentry = nullptr;        // bgrid + bcoarse folded into one word per brick (what the march reads; the two are freed after the build)
     bool bricks = false;
     uint64_t bytes = 0;                // device memory held (volume structures + textures)
 };
@@ -286,6 +287,7 @@ void vrt_scene_free(vrt_ctx* c, vrt_scene* s)
     if (s->bcoarse) hipFree(s->bcoarse);
     if (s->bpool) hipFree(s->bpool);
     if (s->bfine) hipFree(s->bfine);
+    if (s->bentry) hipFree(s->bentry);
     delete s;
 }
 
@@ -502,6 +504,7 @@ int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32
     if (!c || !grid || !palette || !out || (n_bricks && !pool)) return fail(VRT_ERR_INVALID, "vrt_scene_from_bricks: NULL argument");
     if (!nbx || !nby || !nbz || nbx > 512 || nby > 512 || nbz > 512)
         return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_from_bricks: each dimension must be 1..512 bricks (8..4096 voxels)");
+    if (n_bricks >= 0xFFFFFEu) return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_from_bricks: at most 2^24 - 2 occupied bricks (the march's 24-bit brick pointer)");
     const size_t nb = (size_t)nbx * nby * nbz;
     // the brick a pool entry belongs to, as an index into the padded grid; every entry must be referenced exactly once
     std::vector<uint32_t> coord(n_bricks, 0xFFFFFFFFu);
@@ -573,11 +576,17 @@ int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32
         s->n_cells = n_bricks; s->cells_ok = true;
     }
     SCHK(launch_brick_fine(s->bgrid, (int)pbx, (int)pby, coord_dev, n_bricks, s->bpool, s->bfine, c->stream));
+    // what the march reads: pointer, open bits and the eight coarse clearances of a brick in ONE 8-byte word; the pointer grid and
+    // the coarse fields were only needed to build it (and the fine bytes)
+    SCHK(hipMalloc((void**)&s->bentry, npad * 8));
+    SCHK(launch_brick_pack(s->bgrid, s->bcoarse, cstride, npad, s->bentry, c->stream));
     SCHK(hipStreamSynchronize(c->stream));
+    hipFree(s->bgrid); hipFree(s->bcoarse); s->bgrid = nullptr; s->bcoarse = nullptr;
+    s->bytes = npad * 8ull + pool_bytes + fine_bytes + 256 * sizeof(vrt_material) + (uint64_t)n_bricks * 4;
 #undef SCHK
     hipFree(grid_dev); hipFree(coord_dev); hipFree(occ); hipFree(tmp0); hipFree(tmp1);
     grid_dev = coord_dev = nullptr; occ = tmp0 = tmp1 = nullptr;
-    d.bgrid = s->bgrid; d.bcoarse = s->bcoarse; d.bcoarse_stride = cstride; d.bpool = s->bpool; d.bfine = s->bfine;
+    d.bgrid = nullptr; d.bcoarse = nullptr; d.bcoarse_stride = cstride; d.bpool = s->bpool; d.bfine = s->bfine; d.bentry = s->bentry;
     s->d.palette = s->palette;
     {
         const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};

@@ -290,6 +290,24 @@ __global__ __launch_bounds__(256) void k_brick_fine(const uint32_t* __restrict__
     }
 }
 
+// the padded pointer grid and the eight coarse fields folded into the one word per brick the march reads (brick_entry_pack)
+__global__ __launch_bounds__(256) void k_brick_pack(const uint32_t* __restrict__ padded, const uint8_t* __restrict__ coarse, size_t cstride,
+                                                    size_t npad, uint64_t* __restrict__ entry)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    uint8_t c8[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) c8[o] = coarse[(size_t)o * cstride + i];
+    entry[i] = brick_entry_pack(padded[i], c8);
+}
+
+hipError_t launch_brick_pack(const uint32_t* padded, const uint8_t* coarse, size_t cstride, size_t npad, uint64_t* entry, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_brick_pack, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, padded, coarse, cstride, npad, entry);
+    return hipGetLastError();
+}
+
 hipError_t launch_brick_grid(const uint32_t* grid, int nbx, int nby, int nbz, uint32_t* padded, uint8_t* occ, hipStream_t s)
 {
     const size_t n = (size_t)nbx * nby * nbz;

@@ -236,6 +236,7 @@ hipError_t launch_build_pyramid(const uint8_t* vox, int W, int H, int D, uint64_
                                 uint64_t* occ3, hipStream_t s);
 hipError_t launch_build_df(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int cap = 0 /* 0: the dense scene's cap */);
 hipError_t launch_brick_grid(const uint32_t* grid, int nbx, int nby, int nbz, uint32_t* padded, uint8_t* occ, hipStream_t s);
+hipError_t launch_brick_pack(const uint32_t* padded, const uint8_t* coarse, size_t cstride, size_t npad, uint64_t* entry, hipStream_t s);
 hipError_t launch_brick_fine(const uint32_t* padded, int pbx, int pby, const uint32_t* coord, uint32_t n_bricks, const uint8_t* pool,
                              uint8_t* fine, hipStream_t s);
 hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s);

@@ -72,6 +72,10 @@ struct VolumeView {
     const uint8_t*  bfine;      // per occupied brick 8 octants x 512 voxels: 0 = solid, else min(16, side of the largest empty cube
                                 // of VOXELS cornered here ...), looking through the brick's 26 neighbours
     int32_t         pbx, pby;
+    const uint64_t* bentry;     // what a look-up of the march reads: ONE 8-byte word per brick of the padded grid (brick_entry_pack):
+                                // bits 0..23 the pointer (0 empty, 0xFFFFFF border, else 1 + pool index), bits 24..31 "open" per octant,
+                                // bits 32..63 the coarse clearance of the eight octants, four bits each (0 = occupied or border, else
+                                // min(15, bricks)) -- bgrid and bcoarse folded into one load instead of two dependent ones
     uint32_t        df_own;      // 1: AO rays through df_any_loop (development switch)
     uint32_t        df_prefetch; // 1: the secondary rays' look-ups through trace_df_fast prefetch the neighbouring rows (development switch)
     uint32_t        brick_open;  // 1: bit 7 of a coarse byte (no occupied brick is left in the box between this brick and the volume's
@@ -1332,27 +1336,44 @@ VRT_HD void trace_df(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, R
 // brick one byte per voxel and octant (looking through the neighbouring bricks, up to 16 voxels).  Any lower bound of the
 // true clearance gives the same hit (a run only ever skips voxels that are certainly empty), so the result is the dense
 // DF's and the oracle's bit for bit; empty space costs one byte per BRICK in memory and traffic.
+VRT_HD uint64_t brick_entry_pack(uint32_t ptr, const uint8_t coarse[8])
+{
+    // ptr: a padded-grid entry (0 empty, 0xFFFFFFFF border, else 1 + pool index < 0xFFFFFF); coarse[o]: the octant's coarse byte
+    // (low 7 bits: clearance in bricks, 0 = occupied or border; bit 7: open).  A clearance above 15 is stored as 15: any
+    // lower bound of the true clearance gives the same march.
+    uint32_t lo = ptr == 0xFFFFFFFFu ? 0xFFFFFFu : (ptr & 0xFFFFFFu), hi = 0u;
+    for (int o = 0; o < 8; o++) {
+        const uint32_t c = coarse[o] & 0x7Fu;
+        hi |= (c > 15u ? 15u : c) << (4 * o);
+        if (coarse[o] & 0x80u) lo |= 1u << (24 + o);
+    }
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// One look-up of the brick march: the clearance at voxel (mx, my, mz) for a ray of octant `oct` (sx, sy, sz its steps), and the
+// voxel's id where that is 0 inside an occupied brick.  One 8-byte load answers for an empty brick, the border and an open
+// brick; only a lane inside an OCCUPIED brick goes on to its per-voxel byte.  The arithmetic for the empty-brick answer runs
+// for every lane (a dozen instructions, no branch); 32-bit offsets while the padded grid is below 2^29 bricks.
 VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_t oct, int sx, int sy, int sz, uint32_t& material)
 {
-    const int bx = (mx >> 3) + 1, by = (my >> 3) + 1, bz = (mz >> 3) + 1;             // (-1 >> 3 = -1: the border brick)
-    const size_t bi = (size_t)bx + ((size_t)by + (size_t)bz * (size_t)v.pby) * (size_t)v.pbx;
-    uint32_t c = v.bcoarse[(size_t)oct * (size_t)v.bcoarse_stride + bi];
-    if (c & 0x80u) {                                           // an open brick: the march ends here as a miss (material stays 0)
-        if (v.brick_open) return 0u;
-        c &= 0x7Fu;
-    }
+    const uint32_t bx = (uint32_t)((mx >> 3) + 1), by = (uint32_t)((my >> 3) + 1), bz = (uint32_t)((mz >> 3) + 1);   // (-1 >> 3 = -1: the border brick)
+    const uint32_t bi = bx + (uint32_t)mul24((int)by, v.pbx) + (uint32_t)mul24((int)bz, v.pbx * v.pby);
+    const uint64_t e = v.bentry[bi];
+    const uint32_t lo = (uint32_t)e, c = ((uint32_t)(e >> 32) >> (oct * 4u)) & 15u, ptr = lo & 0xFFFFFFu;
     const uint32_t lx = (uint32_t)mx & 7u, ly = (uint32_t)my & 7u, lz = (uint32_t)mz & 7u;
-    if (c != 0u) {                                             // an empty brick with c - 1 empty bricks behind it on every axis
-        const uint32_t rx = sx > 0 ? 8u - lx : lx + 1u, ry = sy > 0 ? 8u - ly : ly + 1u, rz = sz > 0 ? 8u - lz : lz + 1u;
-        const uint32_t k = (c - 1u) * 8u + umin3(rx, ry, rz);
-        return k < 127u ? k : 127u;
+    // an empty brick with c - 1 empty bricks behind it on every axis: the room to the brick's far face is (l ^ 7) + 1 looking
+    // up an axis, l + 1 looking down
+    const uint32_t rx = (lx ^ (sx > 0 ? 7u : 0u)) + 1u, ry = (ly ^ (sy > 0 ? 7u : 0u)) + 1u, rz = (lz ^ (sz > 0 ? 7u : 0u)) + 1u;
+    uint32_t k = (c - 1u) * 8u + umin3(rx, ry, rz);
+    k = k < 127u ? k : 127u;
+    const bool open = v.brick_open != 0u && ((lo >> (24u + oct)) & 1u) != 0u;     // an open brick: the march ends here as a miss
+    uint32_t clear = (c != 0u && !open) ? k : 0u;                                  // (c == 0 and no pool brick: the border -- the ray has left)
+    if (c == 0u && ptr - 1u < 0xFFFFFEu) {
+        const uint32_t l = lx | (ly << 3) | (lz << 6);
+        clear = v.bfine[(size_t)(ptr - 1u) * 4096u + (size_t)(oct * 512u + l)];
+        if (clear == 0u) material = v.bpool[(size_t)(ptr - 1u) * 512u + (size_t)l];
     }
-    const uint32_t ptr = v.bgrid[bi];
-    if (ptr + 1u <= 1u) return 0u;                             // the border (0xFFFFFFFF): the ray has left the volume
-    const size_t l = (size_t)lx + (size_t)ly * 8u + (size_t)lz * 64u;
-    const uint32_t f = v.bfine[((size_t)(ptr - 1u) * 8u + (size_t)oct) * 512u + l];
-    if (f == 0u) material = v.bpool[(size_t)(ptr - 1u) * 512u + l];
-    return f;
+    return clear;
 }
 
 template <class STATS, bool ANYHIT = false>
@@ -1381,6 +1402,9 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
     const float kInf = u2f(0x7F800000u);
     const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
     uint32_t i = 0;
+#if defined(VRT_TRACE_COUNTERS)
+    uint32_t n_look = 0, n_occ = 0;                            // development: look-ups of this lane, and those inside occupied bricks
+#endif
     for (;;) {
         if (!done) {
             if (i >= maxSteps) {
@@ -1392,6 +1416,14 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
                 uint32_t m = 0u;
                 clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m);
                 st_lookup(stats);
+#if defined(VRT_TRACE_COUNTERS)
+                n_look++;
+                {
+                    const uint32_t bi_ = (uint32_t)((s.mx >> 3) + 1) + (uint32_t)(((s.my >> 3) + 1) * v.pbx) + (uint32_t)(((s.mz >> 3) + 1) * v.pbx * v.pby);
+                    const uint64_t e_ = v.bentry[bi_];
+                    if ((((uint32_t)(e_ >> 32) >> (oct * 4u)) & 15u) == 0u) n_occ++;
+                }
+#endif
                 if (clear == 0u) {                             // solid, or the border: the ray has left the volume
                     if (oob(v, s.mx, s.my, s.mz)) fetches = i;
                     else { material = m; fetches = i + 1u; }
@@ -1440,6 +1472,9 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     finish(s, material, lmask, fetches, r);
+#if defined(VRT_TRACE_COUNTERS)
+    r.dbg0 = n_look; r.dbg1 = n_occ;
+#endif
 #else
     finish(s, material, (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2), fetches, r);
 #endif
