@@ -180,6 +180,10 @@ int  vrt_scene_from_dense(vrt_ctx* ctx, const uint8_t* voxels, uint32_t W, uint3
  * (4.5 KiB: ids + per-voxel clearance) plus 12 bytes per brick of the grid.  Only VRT_TRAVERSAL_AUTO applies to it. */
 int  vrt_scene_from_bricks(vrt_ctx* ctx, const uint32_t* grid, uint32_t nbx, uint32_t nby, uint32_t nbz,
                            const uint8_t* pool, uint32_t n_bricks, const vrt_material palette[256], vrt_scene** out);
+/* Drops what a scene holds only for diagnostics: the second set of clearance fields (without open cells) that the first launch
+ * with a count plane (steps_primary / steps_total) builds -- as large as the first, 9 x the padded voxel bytes.  A later launch
+ * with count planes builds it again.  Callers that never attach count planes never hold it.  Waits for the context's stream. */
+int  vrt_scene_trim(vrt_ctx* ctx, vrt_scene* scene);
 /* Device bytes a scene holds (volume, clearance, pyramid / brick structures, palette, sky, noise). */
 int  vrt_scene_memory(const vrt_scene* sc, uint64_t* bytes);
 /* Host-only half of the loader (no device needed): parse + flatten into malloc'd host memory.

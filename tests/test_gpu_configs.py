@@ -4,7 +4,7 @@ frame must equal the unsharded one."""
 import numpy as np
 import pytest
 
-from helpers import compare_planes, metallic_palette
+from helpers import camera_push, compare_planes, metallic_palette
 
 pytestmark = pytest.mark.gpu
 
@@ -194,4 +194,25 @@ def test_volume_past_the_32bit_field_limit(vrt, oracle, engine):
     osn = oracle.OracleScene(vol, pal)
     for r0 in (40, 176, 300):
         assert not _check_band(vrt, oracle, g, osn, push, st, r0, r0 + 4, names)
+    sc.destroy()
+
+
+def test_count_planes_fields_are_built_on_demand_and_can_be_dropped(vrt, engine):
+    """A launch with a count plane marches a second set of clearance fields (without open cells), built on first use: the scene
+    grows by that much, VoxelScene.trim() gives it back, the next such launch builds it again with the same counts."""
+    vol = vrt.synthetic.treehouse(64, seed=3)
+    sc = vrt.VoxelScene.from_dense(engine, vol, metallic_palette(vrt), sky=vrt.synthetic.sky_gradient(32, 16), noise=vrt.synthetic.blue_noise_standin(32))
+    st = vrt.VoxelRenderSettings.primary_only((128, 96))
+    push = camera_push(vrt, (64, 64, 64), (128, 96))
+    base = sc.memory_bytes()
+    vrt.GeometryStage(engine, st, sc).record(push); engine.synchronize()
+    assert sc.memory_bytes() == base                                  # ordinary launches never build it
+    a = vrt.GeometryStage(engine, st, sc, debug_planes=True).record(push); engine.synchronize()
+    steps = a.steps_primary.clone()
+    grown = sc.memory_bytes()
+    assert grown > base + 8 * 66 ** 3
+    sc.trim()
+    assert sc.memory_bytes() == base
+    b = vrt.GeometryStage(engine, st, sc, debug_planes=True).record(push); engine.synchronize()
+    assert (b.steps_primary == steps).all() and sc.memory_bytes() == grown
     sc.destroy()

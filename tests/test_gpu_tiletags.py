@@ -185,3 +185,43 @@ def test_tags_with_arbitrary_camera_bases(vrt, oracle, engine):
             exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=PRODUCT, nthreads=8)
             assert not compare_planes(a, exp, PRODUCT), ("oracle", case)
     sc.destroy()
+
+
+def test_tags_at_the_edges_of_what_the_bound_admits(vrt, oracle, engine):
+    """The tags' projection is used only while its own error bound is below 1.5 px (csrc/vrt_tags.h; tests/test_tile_tag_bound.py
+    checks the bound against exact arithmetic).  Here the renders: camera bases whose direction leans into the plane of right and
+    up by factors from 1e-1 to 1e-6 (the determinant shrinks, the bound grows until the tags switch themselves off), cameras
+    whose plane cuts through or grazes the volume, frames 8 pixels wide and 3840 x 2160 -- tags on, off and the oracle agree."""
+    vol = vrt.synthetic.floating_cubes(40, seed=33, count=40)
+    pal = metallic_palette(vrt)
+    sky = vrt.synthetic.sky_gradient(16, 8)
+    sc = vrt.VoxelScene.from_dense(engine, vol, pal, sky=sky)
+    osn = oracle.OracleScene(vol, pal, sky=sky)
+    planes = GB + ["hit_id"]
+    cases = []
+    for e in (1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6):                  # nearly coplanar bases
+        push = camera_push(vrt, (40, 40, 40), (104, 72), pos=(21.0, 19.0, -55.0), yaw=88.0, pitch=3.0)
+        r = np.array(list(push.cam_right)[:3], np.float64); u = np.array(list(push.cam_up)[:3], np.float64); d = np.array(list(push.cam_dir)[:3], np.float64)
+        d2 = 0.8 * r + 0.5 * u + e * d
+        push.cam_dir[:3] = [float(x) for x in d2]
+        cases.append(("coplanar %g" % e, (104, 72), push))
+    for dist in (0.5, 2.0, 6.0, 20.5):                               # the camera plane grazing / cutting the cells
+        cases.append(("grazing %g" % dist, (104, 72), camera_push(vrt, (40, 40, 40), (104, 72), pos=(-dist, 20.3, 20.1), yaw=90.0, pitch=0.0)))
+        cases.append(("grazing up %g" % dist, (104, 72), camera_push(vrt, (40, 40, 40), (104, 72), pos=(20.2, 40.0 + dist, 19.7), yaw=10.0, pitch=-3.0)))
+    cases.append(("8 wide", (8, 120), camera_push(vrt, (40, 40, 40), (8, 120), pos=(20.0, 20.0, -60.0))))
+    cases.append(("8 high", (200, 8), camera_push(vrt, (40, 40, 40), (200, 8), pos=(20.0, 20.0, -60.0))))
+    cases.append(("4K", (3840, 2160), camera_push(vrt, (40, 40, 40), (3840, 2160), pos=(20.3, 21.1, -70.0), yaw=91.0, pitch=-1.0, jitter=(0.25, -0.4))))
+    for name, res, push in cases:
+        st = vrt.VoxelRenderSettings.primary_only(res)
+        a = _render(vrt, engine, sc, st, push, True, planes)
+        b = _render(vrt, engine, sc, st, push, False, planes)
+        bad = compare_planes(a, b, planes)
+        assert not bad, (name, bad[:2])
+        if res[0] * res[1] < 100000:
+            exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=planes, nthreads=8)
+            assert not compare_planes(a, exp, planes), ("oracle", name)
+        else:                                                      # 4K: bands against the oracle
+            for r0 in (0, 1076, 2152):
+                exp = oracle.render_band(osn, push, oracle.params_from(st.to_c()), r0, r0 + 8, planes=planes, nthreads=8)
+                assert not compare_planes({k: v[r0:r0 + 8] for k, v in a.items()}, exp, planes), ("oracle", name, r0)
+    sc.destroy()

@@ -1,0 +1,137 @@
+"""The tile tags' projection (csrc/vrt_tags.h; k_tile_tags) against exact arithmetic: a block of pixels without a tag is not
+traced, so the screen rectangle the fp32 code computes for a cell must contain the true rectangle once grown by the margin.
+The code reports a bound (ex, ey) on its own rounding error and uses a rectangle only while the bound is <= 1.5 px (the tags
+grow by 2 px, half a pixel of which the pixel-centre convention takes).  Here, on the CPU with the same header:
+  * over random and adversarial cameras (nearly coplanar bases, cells grazing the camera plane, cameras a long way out, frames
+    from 8 to 16384 pixels wide) the TRUE rectangle -- exact rational arithmetic on the same fp32 inputs -- lies inside the
+    computed one grown by the reported bound, with v_rcp_f32 off by -1, 0 or +1 ulp;
+  * a cell with a corner on or behind the camera plane is never reported usable;
+  * for ordinary cameras the bound is a small fraction of a pixel (the rule is not vacuous, and does not switch tags off);
+  * the constants: margin 2 px, limit 1.5 px -- the test fails if they drift apart."""
+import ctypes as C
+import os
+import re
+import subprocess
+from fractions import Fraction as Fr
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "tags_host.cpp")
+LIB = os.path.join(ROOT, "tests", "native", "libtags_host.so")
+HDR = os.path.join(ROOT, "voxel-raytracing_amd", "csrc", "vrt_tags.h")
+
+
+@pytest.fixture(scope="module")
+def tags():
+    if not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(p) for p in (SRC, HDR)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB, SRC])
+    l = C.CDLL(LIB)
+    l.tags_project.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    return l
+
+
+def project(l, cams, cells, ulps=0):
+    cams, cells = np.ascontiguousarray(cams, np.float32), np.ascontiguousarray(cells, np.float32)
+    out = np.zeros((len(cams), 7), np.float32)
+    l.tags_project(len(cams), cams.ctypes.data, cells.ctypes.data, ulps, out.ctypes.data)
+    return out
+
+
+def true_rect(cam, cell):
+    """exact: corners of the cell through [U V C] (a l, b l, l)^T = p - cam; returns (X0, X1, Y0, Y1, min lambda sign)"""
+    f = [Fr(float(v)) for v in cam]
+    U, V, Cv, cp, W, H = f[0:3], f[3:6], f[6:9], f[9:12], f[12], f[13]
+    def cross(a, b): return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+    def dot(a, b): return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+    c0, c1, c2 = cross(V, Cv), cross(Cv, U), cross(U, V)
+    det = dot(U, c0)
+    lo, ext = [Fr(float(v)) for v in cell[:3]], Fr(float(cell[3]))
+    xs, ys, lam = [], [], []
+    for k in range(8):
+        p = [lo[0] + (ext if k & 1 else 0) - cp[0], lo[1] + (ext if k & 2 else 0) - cp[1], lo[2] + (ext if k & 4 else 0) - cp[2]]
+        A, B, L = dot(p, c0), dot(p, c1), dot(p, c2)
+        if det == 0 or L == 0:
+            return None
+        lam.append(L / det)
+        xs.append(A / L * W / 2 + W / 2); ys.append(B / L * H / 2 + H / 2)
+    return min(xs), max(xs), min(ys), max(ys), min(lam)
+
+
+def camera(rng, kind):
+    """(U, V, C, cam, W, H) as the kernel sees them"""
+    yaw, pitch = rng.uniform(0, 2 * np.pi), rng.uniform(-1.4, 1.4)
+    d = np.array([np.cos(pitch) * np.cos(yaw), np.sin(pitch), np.cos(pitch) * np.sin(yaw)])
+    r = np.cross(d, [0, 1, 0]); r /= np.linalg.norm(r)
+    up = np.cross(r, d)
+    W, H = [(1920, 1080), (3840, 2160), (8, 8), (16384, 9216), (131, 77)][rng.integers(0, 5)]
+    fov = rng.uniform(0.3, 1.6)
+    U, V, Cv = r * fov, up * fov * H / W, d.copy()
+    if kind == "skewed":                                        # a basis that is nearly coplanar: C almost in the plane of U and V
+        Cv = U * rng.uniform(-1, 1) + V * rng.uniform(-1, 1) + d * 10.0 ** rng.uniform(-6, -1)
+    if kind == "jitter":
+        Cv = Cv + np.array([rng.uniform(-1, 1) / W * -2, rng.uniform(-1, 1) / H * 2, 0.0])
+    dist = 10.0 ** rng.uniform(0, 5) if kind == "far" else 10.0 ** rng.uniform(0.5, 3.2)
+    cam = np.array([128.0, 128.0, 128.0]) - d * dist + rng.uniform(-40, 40, 3)
+    return np.concatenate([U, V, Cv, cam, [W, H]]).astype(np.float32)
+
+
+def cell(rng, cam, kind):
+    cs = [4, 8][rng.integers(0, 2)]
+    if kind == "grazing":                                       # a cell whose corners straddle or hug the camera plane
+        c = cam.astype(np.float64)
+        U, V, Cv, cp = c[0:3], c[3:6], c[6:9], c[9:12]
+        p = cp + U * rng.uniform(-3, 3) * 50 + V * rng.uniform(-3, 3) * 50 + Cv / np.linalg.norm(Cv) * 10.0 ** rng.uniform(-3, 1)
+        lo = np.floor(p / cs) * cs - 1.0
+    else:
+        lo = rng.integers(0, 2048 // cs, 3) * cs - 1.0
+    return np.array([lo[0], lo[1], lo[2], cs + 2.0], np.float32)
+
+
+def test_margin_constants():
+    src = open(HDR).read()
+    m = float(re.search(r"#define VRT_TAG_MARGIN_PX ([0-9.]+)f", src).group(1))
+    e = float(re.search(r"#define VRT_TAG_ERR_MAX_PX ([0-9.]+)f", src).group(1))
+    assert m == 2.0 and e == 1.5 and e <= m - 0.5              # half a pixel of the margin belongs to the pixel-centre convention
+
+
+@pytest.mark.parametrize("kind", ["ordinary", "jitter", "skewed", "far", "grazing"])
+def test_true_rectangle_lies_inside_the_computed_one_grown_by_its_bound(tags, kind):
+    rng = np.random.default_rng({"ordinary": 1, "jitter": 2, "skewed": 3, "far": 4, "grazing": 5}[kind])
+    n = 1500
+    cams = np.stack([camera(rng, kind if kind != "grazing" else "ordinary") for _ in range(n)])
+    cells = np.stack([cell(rng, cams[i], kind) for i in range(n)])
+    usable = in_front = 0
+    for ulps in (-1, 0, 1):
+        out = project(tags, cams, cells, ulps)
+        for i in range(n):
+            x0, x1, y0, y1, ex, ey, st = (float(v) for v in out[i])
+            t = true_rect(cams[i], cells[i])
+            st = int(st)
+            if t is None or t[4] <= 0:                          # a corner on or behind the camera plane: never usable
+                assert st & 1, (kind, i, ulps, t and float(t[4]))
+                continue
+            in_front += t[4] > Fr(1, 2)                         # every corner at least half a unit of C in front of the camera plane
+            if st & 1:
+                continue                                        # "nothing is known": always allowed
+            X0, X1, Y0, Y1, _ = t
+            assert X0 >= Fr(x0) - Fr(ex) and X1 <= Fr(x1) + Fr(ex), (kind, i, ulps, float(X0), x0, float(X1), x1, ex)
+            assert Y0 >= Fr(y0) - Fr(ey) and Y1 <= Fr(y1) + Fr(ey), (kind, i, ulps, float(Y0), y0, float(Y1), y1, ey)
+            if st == 0:
+                assert ex <= 1.5 and ey <= 1.5
+                usable += t[4] > Fr(1, 2)
+    if kind in ("ordinary", "jitter"):
+        assert in_front > n and usable > 0.97 * in_front, (usable, in_front)      # the rule does not switch the tags off for sane cameras
+
+
+def test_bound_is_a_small_fraction_of_a_pixel_for_the_bench_camera(tags, vrt):
+    """the bench line's camera and every occupied 4^3 cell position of a 256^3 volume's extreme corners: bound below 0.01 px"""
+    pos0, yaw, pitch = vrt.synthetic.default_camera_for(256, 256, 256)
+    push = vrt.make_push(vrt.CameraController(position=pos0, yaw=yaw, pitch=pitch), (256, 256, 256), (1920, 1080))
+    cd = np.array(push.cam_dir[:3], np.float32); cd = cd / np.float32(np.sqrt(np.float32((cd * cd).sum())))
+    U = np.array(push.cam_right[:3], np.float32); V = np.array(push.cam_up[:3], np.float32) * np.float32(1080) / np.float32(1920)
+    cam = np.concatenate([U, V, cd, np.array(push.cam_pos[:3], np.float32), [1920, 1080]]).astype(np.float32)
+    cells = np.array([[x, y, z, 6.0] for x in (-1.0, 123.0, 251.0) for y in (-1.0, 123.0, 251.0) for z in (-1.0, 123.0, 251.0)], np.float32)
+    out = project(tags, np.repeat(cam[None], len(cells), 0), cells)
+    assert (out[:, 6] == 0).all() and out[:, 4].max() < 0.01 and out[:, 5].max() < 0.01, out[:, 4:7]

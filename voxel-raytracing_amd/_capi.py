@@ -78,6 +78,7 @@ SYMBOLS = {
     "vrt_scene_from_dense": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Material), C.POINTER(_P)]),
     "vrt_scene_from_bricks": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(Material), C.POINTER(_P)]),
     "vrt_scene_memory": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "vrt_scene_trim": (C.c_int, [_P, _P]),
     "vrt_comm_unique_id": (C.c_int, [_P]),
     "vrt_comm_init_rank": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "vrt_comm_init_all": (C.c_int, [C.c_int32, C.POINTER(_P), C.POINTER(_P)]),

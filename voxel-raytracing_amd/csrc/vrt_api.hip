@@ -607,6 +607,20 @@ bad:
     return rc;
 }
 
+int vrt_scene_trim(vrt_ctx* c, vrt_scene* s)
+{
+    if (!c || !s) return fail(VRT_ERR_INVALID, "vrt_scene_trim: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::lock_guard<std::mutex> lock(s->lazy);
+    if (s->df_counts) {
+        hipFree(s->df_counts - s->df_guard);
+        s->df_counts = nullptr;
+        s->bytes -= s->df_bytes;
+    }
+    return VRT_OK;
+}
+
 int vrt_scene_memory(const vrt_scene* s, uint64_t* bytes)
 {
     if (!s || !bytes) return fail(VRT_ERR_INVALID, "vrt_scene_memory: NULL argument");

@@ -1164,41 +1164,27 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
     const float ext = (float)cs + 2.0f;
     const float lo[3] = {(float)((cell & 1023u) * cs) - 1.0f, (float)(((cell >> 10) & 1023u) * cs) - 1.0f, (float)((cell >> 20) * cs) - 1.0f};
     uint32_t* tags = P.tile_tags + (size_t)frame * P.tags_per_frame;
-    // ray of screen position (a, b) in [-1, 1]^2: C + a U + b V (frag:312-319); [U V C] (a, b, lambda)^T = p - cam
-    const float V[3] = {g.planeV.x, g.planeV.y, g.planeV.z};
-    const float C[3] = {g.cd.x + g.jx, g.cd.y + g.jy, g.cd.z};
-    const float c0[3] = {V[1] * C[2] - V[2] * C[1], V[2] * C[0] - V[0] * C[2], V[0] * C[1] - V[1] * C[0]};   // V x C
-    const float c1[3] = {C[1] * U[2] - C[2] * U[1], C[2] * U[0] - C[0] * U[2], C[0] * U[1] - C[1] * U[0]};   // C x U
-    const float c2[3] = {U[1] * V[2] - U[2] * V[1], U[2] * V[0] - U[0] * V[2], U[0] * V[1] - U[1] * V[0]};   // U x V
-    const float det = U[0] * c0[0] + U[1] * c0[1] + U[2] * c0[2];
-    const float scale = (fabsf(U[0]) + fabsf(U[1]) + fabsf(U[2])) * (fabsf(V[0]) + fabsf(V[1]) + fabsf(V[2])) * (fabsf(C[0]) + fabsf(C[1]) + fabsf(C[2]));
-    bool all = !(fabsf(det) > 1e-3f * scale);
-    const float rdet = 1.0f / det;
-    // a, b, lambda are linear in p: the corner's numerators once, the other seven corners by additions (a / lambda needs no
-    // determinant); the depth test once per cell, on the smallest lambda against the farthest corner's reach
-    const float p0[3] = {lo[0] - cam[0], lo[1] - cam[1], lo[2] - cam[2]};
-    const float A0 = p0[0] * c0[0] + p0[1] * c0[1] + p0[2] * c0[2], B0 = p0[0] * c1[0] + p0[1] * c1[1] + p0[2] * c1[2];
-    const float L0 = p0[0] * c2[0] + p0[1] * c2[1] + p0[2] * c2[2];
-    const float hw = 0.5f * g.W, hh = 0.5f * g.H;
-    float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f, lam_min = 1e30f;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const float ex = (k & 1) ? ext : 0.0f, ey = (k & 2) ? ext : 0.0f, ez = (k & 4) ? ext : 0.0f;
-        const float An = A0 + (ex * c0[0] + ey * c0[1] + ez * c0[2]), Bn = B0 + (ex * c1[0] + ey * c1[1] + ez * c1[2]);
-        const float Ln = L0 + (ex * c2[0] + ey * c2[1] + ez * c2[2]);
-        lam_min = fminf(lam_min, Ln * rdet);
-        const float rl = __builtin_amdgcn_rcpf(Ln);          // (1 ulp: the rectangle has two pixels of margin)
-        const float fx = An * rl * hw + hw, fy = Bn * rl * hh + hh;
-        x0 = fminf(x0, fx); x1 = fmaxf(x1, fx); y0 = fminf(y0, fy); y1 = fmaxf(y1, fy);
+    // the cell's screen rectangle and the bound on its error (vrt_tags.h: the projection, its rounding analysis and the rule
+    // that a rectangle is only used while its bound is below what the two pixels of margin absorb)
+    TagCam tc;
+    tc.U[0] = U[0]; tc.U[1] = U[1]; tc.U[2] = U[2];
+    tc.V[0] = g.planeV.x; tc.V[1] = g.planeV.y; tc.V[2] = g.planeV.z;
+    tc.C[0] = g.cd.x + g.jx; tc.C[1] = g.cd.y + g.jy; tc.C[2] = g.cd.z;
+    tc.cam[0] = cam[0]; tc.cam[1] = cam[1]; tc.cam[2] = cam[2];
+    tc.W = g.W; tc.H = g.H;
+    float x0, x1, y0, y1, ex, ey;
+    const int st = tag_project(tc, lo, ext, x0, x1, y0, y1, ex, ey);
+    bool all = (st & 1) != 0;
+    const float m = VRT_TAG_MARGIN_PX;
+    if (!all) {
+        // off the screen by more than the margin AND more than its own error bound: nothing to tag, whatever the bound is
+        const float gx = fmaxf(m, ex + 0.5f), gy = fmaxf(m, ey + 0.5f);
+        if (x1 + gx < 0.0f || y1 + gy < 0.0f || x0 - gx > g.W || y0 - gy > g.H) return;
+        if (st & 2) all = true;
     }
-    // behind the camera plane, or at a grazing angle to it (where fp32 no longer places the corner to a fraction of a pixel)
-    if (!(lam_min > 0.01f * (fabsf(p0[0] + 0.5f * ext) + fabsf(p0[1] + 0.5f * ext) + fabsf(p0[2] + 0.5f * ext) + 1.5f * ext))) all = true;
-    if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) all = true;
-    const float m = 2.0f;
     int tx0 = (int)floorf(fmaxf(x0 - m, 0.0f) * 0.125f), tx1 = (int)floorf(fminf(x1 + m, g.W - 1.0f) * 0.125f);
     int ty0 = (int)floorf(fmaxf(y0 - m, 0.0f) * 0.125f), ty1 = (int)floorf(fminf(y1 + m, g.H - 1.0f) * 0.125f);
-    if (!all && (x1 + m < 0.0f || y1 + m < 0.0f || x0 - m > g.W || y0 - m > g.H)) return;      // off screen
-    if (!all && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 1024) all = true;                           // too close to bound cheaply
+    if (!all && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 1024) all = true;                           // (a cell that covers the screen: tagging it costs more than it saves)
     if (all) { tags[P.tags_per_frame - 1u] = P.tile_gen; return; }
     // screen row of blocks -> the row K1 finds it in: the launch's local rows (the strips this frame's rank owns), in dispatch
     // order (tile_origin: bottom rows first)

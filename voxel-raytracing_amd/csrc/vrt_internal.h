@@ -8,6 +8,7 @@
 #include "../../include/vrt.h"
 #include "vrt_traverse.h"
 #include "vrt_sky.h"
+#include "vrt_tags.h"
 
 namespace vrt {
 

@@ -375,6 +375,10 @@ class VoxelScene:
             s.set_blue_noise(noise)
         return s
 
+    def trim(self) -> None:
+        """Drop the diagnostic copy of the clearance fields a launch with count planes built (vrt_scene_trim)."""
+        check(lib().vrt_scene_trim(self.engine.ctx, self._h))
+
     def memory_bytes(self) -> int:
         n = C.c_uint64()
         check(lib().vrt_scene_memory(self._h, C.byref(n)))
