@@ -19,7 +19,8 @@ CSRC = os.path.join(ROOT, "voxel-raytracing_amd", "csrc")
 BUDGET = {
     "k_primaryILi7ELb0ELi1ELb0ELi0EE": ("K1 primary-only, look-up loop, one frame per launch (rows dealt to the XCDs)", 64, 80, 0),
     "k_primaryILi7ELb0ELi1ELb0ELi2EE": ("K1 primary-only, look-up loop, 8 frames in the kernel arguments (XCD regions)", 64, 80, 0),
-    "k_primaryILi7ELb0ELi1ELb1ELi2EE": ("K1 primary-only, look-up loop, slots in the table (the bench line's kernel)", 64, 80, 0),
+    "k_primaryILi7ELb0ELi1ELb1ELi0EE": ("K1 primary-only, look-up loop, slots in the table, rows dealt to the XCDs (the bench line's kernel)", 64, 80, 0),
+    "k_primaryILi7ELb0ELi1ELb1ELi2EE": ("K1 primary-only, look-up loop, slots in the table, XCD regions", 64, 80, 0),
     "k_primaryILi7ELb0ELi4ELb0ELi0EE": ("megakernel without its bounce loop, one frame per launch", 64, 80, 0),
     "k_primaryILi7ELb0ELi4ELb1ELi2EE": ("megakernel without its bounce loop, table", 72, 96, 0),
     "k_primaryILi7ELb0ELi2ELb0ELi0EE": ("megakernel, one frame per launch (7 waves per SIMD by design)", 72, 96, 480),
