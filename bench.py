@@ -11,7 +11,9 @@ into screen strips that are dealt to the N ranks.  A rank traces its strips of A
 (vrt_render_geometry_batch / _slots: the next frame's tiles are dispatched while the previous frame drains), packs
 them, and ONE RCCL collective per step moves the strips to where the frames are assembled: frame block b (F frames) is
 gathered to rank b, the N gathers issued as a single all-to-all so that every GPU receives over all of its xGMI links
-(VRT_ASSEMBLE=root: everything to rank 0 with one dist.gather instead -- bound by rank 0's inbound links).  The strip
+(VRT_ASSEMBLE=root: everything to rank 0 with one dist.gather instead -- bound by rank 0's inbound links).  A finished frame
+stays where the collective put it: N row bands, each a contiguous block of the receive buffer, in row order
+(ShardedBatch(in_place=True); finals[j] makes a contiguous copy when asked, as the end-of-run comparison does).  The strip
 assignment is rotated per block, so every rank traces the same number of rows per step although 1080 rows are 67.5
 strips.  The collective of a step runs while the next step is traced.  Per-GPU work per step is therefore F frames'
 worth of rays at every N ("weak" scaling); value = total primary rays of all ranks / wall time.  At N = 1 there is no
@@ -369,7 +371,7 @@ def main():
         pushes.append(renderer.push_constants())
     assemble_on = os.environ.get("VRT_ASSEMBLE", "owners")     # where finished frames end up: "owners" | "root"
     sb = vrt.distributed.ShardedBatch(renderer._geometryStage, F, rank, world, host_staged=(backend != "nccl"),
-                                      assemble_on=assemble_on, direct="only")
+                                      assemble_on=assemble_on, direct="only", in_place=True)
     launches_per_step = (F + 255) // 256                      # K1 launches per rank and step (VRT_MAX_TABLE frames each)
 
     overlap = os.environ.get("VRT_SYNC_GATHER", "0") != "1"

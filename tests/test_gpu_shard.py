@@ -153,8 +153,8 @@ def test_sharded_batch_assembles_to_the_unsharded_frames(vrt, engine):
     assert any((ref[f] != ref[0]).any().item() for f in range(1, F))
 
 
-@pytest.mark.parametrize("rotate", [True, False])
-def test_sharded_batch_owner_blocks_assemble_to_the_unsharded_frames(vrt, engine, rotate):
+@pytest.mark.parametrize("rotate,in_place", [(True, False), (False, False), (True, True)])
+def test_sharded_batch_owner_blocks_assemble_to_the_unsharded_frames(vrt, engine, rotate, in_place):
     """ShardedBatch(assemble_on="owners"): frame block b ends up on rank b.  The all-to-all is replaced by device copies
     (chunk d of rank s's send buffer -> chunk s of rank d's receive buffer); 136 rows = 8.5 strips over 3 ranks, so the
     ranks own different numbers of rows and the rotation of the strip assignment per block matters."""
@@ -166,8 +166,9 @@ def test_sharded_batch_owner_blocks_assemble_to_the_unsharded_frames(vrt, engine
     st = vrt.VoxelRenderSettings.primary_only(res)
     pushes = [vrt.make_push(vrt.CameraController(position=(24.0 + f, 25.0, -40.0 + 2.0 * f)), (48, 48, 48), res) for f in range(F)]
     ref = [g.color.clone() for g in vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, 0, 1).step(pushes)]
-    ranks = [vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, r, N, assemble_on="owners", rotate=rotate)
+    ranks = [vrt.distributed.ShardedBatch(vrt.GeometryStage(engine, st, sc), F, r, N, assemble_on="owners", rotate=rotate, in_place=in_place)
              for r in range(N)]
+    assert all(sb.in_place == in_place for sb in ranks)       # (with the rotation: one band of 48 rows per rank)
     recv = [sb.recv_buffers() for sb in ranks]
     for s, sb in enumerate(ranks):
         sb.render(pushes)
@@ -181,6 +182,11 @@ def test_sharded_batch_owner_blocks_assemble_to_the_unsharded_frames(vrt, engine
         assert list(sb.owned_frames()) == list(range(d * FB, (d + 1) * FB))
         for j, f in enumerate(sb.owned_frames()):
             assert (finals[j] == ref[f]).all(), (d, f)
+            if in_place:                                       # the frame as a consumer walks it: N bands of the receive buffer, in row order
+                bands = finals.bands(j)
+                assert [r0 for r0, _ in bands] == sorted(r0 for r0, _ in bands) and sum(t.shape[0] for _, t in bands) == res[1]
+                for r0, t in bands:
+                    assert t.is_contiguous() and (t == ref[f][r0:r0 + t.shape[0]]).all()
         # rows this rank traces per step: equal over the ranks only with the rotation
         rows.append(sum(len(vrt.distributed.owned_rows(res[1], sb.virtual_rank(d, b), N, sb.strip_rows)) for b in range(N)))
     assert sum(rows) == N * res[1]

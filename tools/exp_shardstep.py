@@ -27,7 +27,7 @@ direct = False if "copy" in sys.argv[1:] else ("only" if "only" in sys.argv[1:] 
 for N in (1, 2, 4, 8):
     for mode in modes:
         F = N * 8
-        sb = vrt.distributed.ShardedBatch(vrt.GeometryStage(eng, st, sc), F, min(1, N - 1), N, assemble_on=mode, direct=direct, side_unpack=("side" in sys.argv[1:]), rotate=(False if "norotate" in sys.argv[1:] else None), strip_rows=(16 if "strips16" in sys.argv[1:] else None))
+        sb = vrt.distributed.ShardedBatch(vrt.GeometryStage(eng, st, sc), F, min(1, N - 1), N, assemble_on=mode, direct=direct, side_unpack=("side" in sys.argv[1:]), rotate=(False if "norotate" in sys.argv[1:] else None), strip_rows=(16 if "strips16" in sys.argv[1:] else None), in_place=("inplace" in sys.argv[1:]))
         pushes = pushes_for(F)
         k1 = timed(lambda: sb.render(pushes))
         if N == 1:

@@ -1189,18 +1189,29 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
     // screen row of blocks -> the row K1 finds it in: the launch's local rows (the strips this frame's rank owns), in dispatch
     // order (tile_origin: bottom rows first)
     const int nranks = P.sh.nranks, rows8 = P.sh.strip_rows >> 3, k = P.tile_h >> 3, T = P.tiles_y_local;
-    for (int ty = ty0; ty <= ty1; ty++) {
-        int local = ty;
-        if (nranks > 1) {
-            const int strip = ty / rows8;
-            if (strip % nranks != shard_rank) continue;
-            local = (strip / nranks) * rows8 + (ty - strip * rows8);
+    if (nranks <= 1) {
+        for (int ty = ty0; ty <= ty1; ty++) {
+            const int tyl = ty / k;                                // the workgroup tile's local row, and the block's row within the tile
+            if (tyl >= T) continue;
+            const uint32_t row = (uint32_t)((T - 1 - tyl) * k + (ty - tyl * k));
+            // (plain stores; looking first whether the block has its tag already -- most are covered by many cells -- measured slower)
+            for (int tx = tx0; tx <= tx1; tx++) tags[row * P.tags_x + (uint32_t)tx] = P.tile_gen;
         }
-        const int tyl = local / k;                             // the workgroup tile's local row, and the block's row within the tile
-        if (tyl >= T) continue;
-        const uint32_t row = (uint32_t)((T - 1 - tyl) * k + (local - tyl * k));
-        // (plain stores; looking first whether the block has its tag already -- most are covered by many cells -- measured slower)
-        for (int tx = tx0; tx <= tx1; tx++) tags[row * P.tags_x + (uint32_t)tx] = P.tile_gen;
+        return;
+    }
+    // sharded: only the strips this frame's rank traces -- strip by strip, not row by row with a test (a rank of eight owns one
+    // band of the screen: seven eighths of a cell's rows are somebody else's)
+    const int s0 = ty0 / rows8, s1 = ty1 / rows8;
+    int s = s0 + ((shard_rank - s0 % nranks) + nranks) % nranks;   // the first strip >= s0 that is dealt to shard_rank
+    for (; s <= s1; s += nranks) {
+        const int a = ty0 > s * rows8 ? ty0 : s * rows8, b = ty1 < (s + 1) * rows8 - 1 ? ty1 : (s + 1) * rows8 - 1;
+        for (int ty = a; ty <= b; ty++) {
+            const int local = (s / nranks) * rows8 + (ty - s * rows8);
+            const int tyl = local / k;
+            if (tyl >= T) continue;
+            const uint32_t row = (uint32_t)((T - 1 - tyl) * k + (local - tyl * k));
+            for (int tx = tx0; tx <= tx1; tx++) tags[row * P.tags_x + (uint32_t)tx] = P.tile_gen;
+        }
     }
 }
 

@@ -215,6 +215,38 @@ class ShardedFrame:
         return self.gather(self.pack(self.render_local()))
 
 
+class _BandFrames:
+    """ShardedBatch(in_place=True).finals: the finished frames of this rank's block as they lie in the receive buffer.
+    bands(j): the row bands of frame j in frame order, [(first row, tensor [rows, W, 4] -- a view), ...];
+    self[j]: a contiguous [H, W, 4] copy, assembled when asked for (tests, the bench's comparison with single-GPU renders)."""
+
+    def __init__(self, sb):
+        self.sb = sb
+
+    def __len__(self):
+        return self.sb.FB
+
+    def bands(self, j: int):
+        sb = self.sb
+        buf = sb._recv[sb._recv_cur]
+        out = []
+        for s in range(sb.nranks):                             # source s traced this block as virtual rank vr: band vr of the frame
+            vr = sb.virtual_rank(s, sb.rank)
+            r0 = vr * sb.strip_rows
+            rows = max(0, min(sb.strip_rows, sb.H - r0))
+            if rows:
+                out.append((r0, buf[s * sb.FB + j][:rows]))
+        return sorted(out, key=lambda t: t[0])
+
+    def __getitem__(self, j: int):
+        import torch
+        sb = self.sb
+        img = torch.empty((sb.H, sb.W, 4), dtype=torch.uint8, device=sb.packed.device)
+        for r0, t in self.bands(j):
+            img[r0:r0 + t.shape[0]].copy_(t)
+        return img
+
+
 class ShardedBatch:
     """Per-rank driver for a batch of F frames (consecutive camera poses): ONE K1 launch over this rank's strips of all of
     them (vrt_render_geometry_batch / _slots), strip packing, ONE collective per step, strip unpacking at the receivers.
@@ -244,7 +276,8 @@ class ShardedBatch:
                             collective."""
 
     def __init__(self, stage, n_frames: int, rank: int, nranks: int, strip_rows: int = None, group=None, host_staged: bool = False,
-                 assemble_on: str = "root", rotate: bool = None, direct: bool = True, side_unpack: bool = False, denoise: bool = False):
+                 assemble_on: str = "root", rotate: bool = None, direct: bool = True, side_unpack: bool = False, denoise: bool = False,
+                 in_place: bool = False):
         import torch
         if denoise and not stage._settings.denoiserSettings.enable:
             raise ValueError("ShardedBatch(denoise=True) with the denoiser switched off in the stage's settings (denoiserSettings.enable)")
@@ -303,7 +336,16 @@ class ShardedBatch:
                             tab[f].color8 = None
                     self._frames.append(tab)
                 self._cur = 1
-            if self.owners:
+            # in_place ("owners" with one band per rank): a finished frame STAYS where the collective put it -- N row bands, each a
+            # contiguous block of the receive buffer, in a known order -- instead of being copied into one [H, W, 4] image: the
+            # copy is a pass over every frame at HBM speed (23 us of a 337 us step at N = 8) for the benefit of a consumer that can
+            # just as well walk eight chunks (bands(j)); finals[j] assembles a contiguous copy when somebody asks for one.
+            self.in_place = bool(in_place) and self.owners and max_local_strips(H, nranks, self.strip_rows) == 1
+            if self.in_place:
+                self.finals = _BandFrames(self)
+                self._recv = None
+                self._recv_cur = 0
+            elif self.owners:
                 self.finals = torch.zeros((self.FB, H, W, 4), dtype=torch.uint8, device=dev)
             elif rank == 0:
                 self.finals = torch.zeros((self.F, H, W, 4), dtype=torch.uint8, device=dev)
@@ -427,6 +469,10 @@ class ShardedBatch:
         tables of the (source, frame) unpack.  "owners" (every rank): one buffer of the same shape as self.packed, laid out
         [source][frame of my block], and the tables of its unpack into self.finals."""
         import torch
+        if getattr(self, "in_place", False):
+            if self._recv is None:                             # two receive buffers: step k's frames are read while step k + 1 arrives
+                self._recv = [torch.empty_like(self.packed), torch.empty_like(self.packed)]
+            return self._recv[self._recv_cur ^ 1]              # the one the NEXT collective fills
         if self._root is None:
             P = C.c_void_p
             if self.owners:
@@ -449,6 +495,9 @@ class ShardedBatch:
     def assemble(self, ctx=None):
         """After the collective filled recv_buffers(): the received strips into self.finals (one launch per 64 (source, frame)
         pairs).  Rank 0 in "root" mode, every rank in "owners" mode.  ctx: another context (stream) to run it on."""
+        if getattr(self, "in_place", False):                   # the collective that just completed filled the other buffer: it is current now
+            self._recv_cur ^= 1
+            return self.finals
         _, n, src, dst, shards = self._root
         _capi.check(_capi.lib().vrt_unpack_rows_batch(ctx or self.stage.engine.ctx, n, src, dst, self.W, self.H, 4, shards))
         return self.finals
