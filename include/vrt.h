@@ -145,7 +145,8 @@ int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle()
 /* Development switches of a context (no reference analogue; the reference's counterpart is recompiling a shader): every
  * one is 1 by default and changes speed only, never a result -- the tests render "the same frame without X" with them.
  * Names: "tile_tags", "box_rect", "xcd_regions", "fast_loop", "no_bounce_kernel", "sky_fast" (looked at by every
- * vrt_render_geometry* call) and "open_cells", "df_prefetch", "df_own" (looked at when a scene is created).  The
+ * vrt_render_geometry* call), "denoise_th16", "denoise_packed" (by vrt_denoise) and "open_cells", "df_prefetch", "df_own"
+ * (looked at when a scene is created).  The
  * environment seeds them ONCE, at vrt_ctx_create (VRT_TILE_TAGS=0, VRT_SKY_FAST=0, ...); nothing on the render path
  * calls getenv.  Unknown name: VRT_ERR_INVALID. */
 int  vrt_ctx_set_option(vrt_ctx* ctx, const char* name, int32_t value);

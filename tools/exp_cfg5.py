@@ -13,6 +13,7 @@ def flag(name, default):
         i = args.index(name); v = args[i + 1]; del args[i:i + 2]; return v
     return default
 ao, sh, bo = int(flag("--ao", "4")), int(flag("--shadows", "1")), int(flag("--bounces", "4"))
+split = int(flag("--split", "0"))
 eng = vrt.Engine(0)
 for a in args:
     k, v = a.split("="); eng.set_option(k, int(v))
@@ -27,6 +28,7 @@ st = vrt.VoxelRenderSettings(targetResolution=(3840, 2160))
 st.fsrSetttings.enable = False
 st.occlusionSettings.numSamples = ao; st.traceSettings.shadows = bool(sh); st.traceSettings.maxReflections = bo; st.traceSettings.maxRaySteps = 6144
 st.denoiserSettings.enable = False
+st.traceSettings.splitKernels = bool(split)
 geo = vrt.GeometryStage(eng, st, sc)
 eng.set_timing(True)
 t = []
@@ -34,4 +36,4 @@ for _ in range(reps + 2):
     geo.record(push); eng.synchronize()
     t.append(eng.last_timings()["geometry_ms"])
 t = sorted(t[2:])
-print(f"{' '.join(args) or 'defaults'} ao={ao} shadows={sh} bounces={bo}: config 5 geometry {t[len(t) // 2]:.3f} ms (min {t[0]:.3f}), scene {sc.memory_bytes() / 1e6:.0f} MB", flush=True)
+print(f"{' '.join(args) or 'defaults'} ao={ao} shadows={sh} bounces={bo} split={split}: config 5 geometry {t[len(t) // 2]:.3f} ms (min {t[0]:.3f}), scene {sc.memory_bytes() / 1e6:.0f} MB", flush=True)

@@ -47,6 +47,8 @@ struct DevOptions {
     int fast_loop = 1;         // AUTO / DF through the hand-written look-up loop
     int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
+    int denoise_th16 = 0;      // the tolerance denoiser on 64 x 16 tiles
+    int denoise_packed = 1;    // the exact weighted pass two taps at a time in packed fp32
     int open_cells = 1;        // (scene build) open cells / open bricks in the clearance fields
     int df_prefetch = 1;       // (scene build) secondary rays' look-ups prefetch the neighbouring rows
     int df_own = 1;            // (scene build) AO rays spend their own clearance
@@ -56,6 +58,7 @@ static const OptName kOptNames[] = {
     {"tile_tags", "VRT_TILE_TAGS", &DevOptions::tile_tags}, {"box_rect", "VRT_BOX_RECT", &DevOptions::box_rect},
     {"xcd_regions", "VRT_XCD_REGIONS", &DevOptions::xcd_regions}, {"fast_loop", "VRT_FAST_LOOP", &DevOptions::fast_loop},
     {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
+    {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
     {"open_cells", "VRT_OPEN_CELLS", &DevOptions::open_cells}, {"df_prefetch", "VRT_DF_PREFETCH", &DevOptions::df_prefetch},
     {"df_own", "VRT_DF_OWN", &DevOptions::df_own},
 };
@@ -1145,6 +1148,7 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
     int rc = make_shard(shard, H, p.sh, nullptr);
     if (rc != VRT_OK) return rc;
     p.normal = normal8; p.position = position; p.W = W; p.H = H; p.mode = ds->mode;
+    p.tile16 = c->opt.denoise_th16; p.no_packed = c->opt.denoise_packed ? 0 : 1;
     uint8_t* targets[2] = {target0, target1};
     const uint8_t* last = color_in;
     if (c->timing) HIPCHK(hipEventRecord(c->ev_den0, c->stream));

@@ -1772,8 +1772,7 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
         size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * (inf ? 16 : 48);   // pass 0 stages the colour plane only
         const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
         if (!inf && (p.mode & VRT_DENOISE_FAST) && p.sh.nranks == 1 && p.extend == 0) {
-            const char* e = getenv("VRT_DENOISE_TH");                        // development switch: tile height 8 / 16
-            const int th = (e && e[0] == '1') ? 16 : 8;
+            const int th = p.tile16 ? 16 : 8;                                // development switch: tile height 8 / 16
             dim3 g2((unsigned)((p.W + 63) / 64), (unsigned)((p.H + th - 1) / th));
             const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(th + 2 * R) * 48;
             if (th == 8) { if (shipped) hipLaunchKernelGGL((k_denoise_fast<true, 8>), g2, block, l2, s, p, R);
@@ -1787,7 +1786,7 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
         }
         else if (inf) { if (shipped) hipLaunchKernelGGL((k_denoise_lds<true, true>), grid, block, lds, s, p, R);
                    else         hipLaunchKernelGGL((k_denoise_lds<true, false>), grid, block, lds, s, p, R); }
-        else if (p.packed_ok && !(getenv("VRT_DENOISE_PACKED") && getenv("VRT_DENOISE_PACKED")[0] == '0')) {   // (development switch: 0 = the tap-by-tap form)
+        else if (p.packed_ok && !p.no_packed) {                              // (development switch: the tap-by-tap form)
             if (shipped) hipLaunchKernelGGL((k_denoise_lds<false, true, false, true>), grid, block, lds, s, p, R);
             else         hipLaunchKernelGGL((k_denoise_lds<false, false, false, true>), grid, block, lds, s, p, R);
         }

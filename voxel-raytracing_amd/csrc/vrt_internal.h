@@ -208,6 +208,8 @@ struct DenoiseParams {
     float   rc, rn, rp, rs;    // RN(1 / phi) per channel, RN(1 / stepWidth^2): the exact kernel's divisions by pass-uniform values
     int32_t packed_ok;         // 1: phi and stepWidth^2 are in the range the division by reciprocal + residuals is exact for
     int32_t extend;            // rows beyond each owned strip that this pass must also produce
+    int32_t tile16;            // development switch (context option "denoise_th16"): the tolerance kernel on 64 x 16 tiles instead of 64 x 8
+    int32_t no_packed;         // development switch (context option "denoise_packed" = 0): the exact weighted pass tap by tap
     ShardMap sh;
 };
 
