@@ -29,3 +29,7 @@ loop(sc, (1920, 1080), 256, 4, 5, 2, 0, 512, (128.0, 128.0, -204.8))
 grid, pool = vrt.synthetic.sparse_brick_scene(2048, 0.015, seed=5)
 sb = vrt.VoxelScene.from_bricks(eng, grid, pool, pal, sky=sky, noise=noise)
 loop(sb, (3840, 2160), 2048, 4, 4, 0, 0, 6144, (1024.3, 1024.2, -1638.4), n=5)
+sb.destroy()
+# BASELINE configs[3]: Mandelbulb 512^3, 3840x2160, 2 bounces, AO 4, shadow ray -- five frames, one per launch
+scm = vrt.VoxelScene.from_dense(eng, vrt.synthetic.mandelbulb(512), pal, sky=sky, noise=noise)
+loop(scm, (3840, 2160), 512, 4, 2, 0, 0, 512, (512 * 0.5 + 0.3, 512 * 0.5 + 0.2, -0.45 * 512), n=5)
