@@ -271,6 +271,39 @@ def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounc
     return out
 
 
+def frames_in_flight(vrt, scene, push, W, H, configs, slots=(1, 2, 3), n=240):
+    """The reference's call pattern with its own MAX_FRAMES_IN_FLIGHT (source/engine/engine.hpp:19): one frame per
+    vrt_render_geometry call, k contexts (a stream and a G-buffer each, one shared scene) taking the calls in turn -- a frame's
+    tail overlaps the next frame's ramp without any batching API.  Wall-clock us per frame over n calls, host enqueue included."""
+    import ctypes as C
+    engines = [vrt.Engine(0, use_torch_stream=False) for _ in range(max(slots))]
+    for e in engines:
+        e.set_timing(False)
+    gbs = [vrt.GeometryBuffer(e, W, H) for e in engines]
+    for e in engines:
+        e.synchronize()
+    frs = [g.to_c() for g in gbs]
+    out = {}
+    for name, st in configs:
+        stc = st.to_c()
+        row = {}
+        for k in slots:
+            def go(m):
+                for j in range(m):
+                    vrt._capi.check(vrt.lib().vrt_render_geometry(engines[j % k].ctx, scene.handle, C.byref(push), C.byref(stc), C.byref(frs[j % k]), None))
+                for e in engines:
+                    e.synchronize()
+            go(12)
+            t0 = time.perf_counter()
+            go(n)
+            row[str(k)] = round((time.perf_counter() - t0) / n * 1e6, 2)
+        out[name] = row
+    for e in engines:
+        e.destroy()
+    return {"us_per_frame": out, "what": "one frame per vrt_render_geometry call, k contexts (frames in flight) taking the calls in turn; wall clock over "
+                                         f"{n} calls, host enqueue included; the reference's Engine keeps MAX_FRAMES_IN_FLIGHT = 2"}
+
+
 def primary_4k(vrt, torch, engine, scene, NV, pos0, yaw, pitch, W=3840, H=2160, nb=16):
     """The headline's workload at 3840x2160: K1 batched (nb frames per launch) and one frame per launch."""
     import numpy as np
@@ -507,6 +540,11 @@ def main():
                 ("configs[2]: primary + shadow ray, 1 denoiser pass", 0, True, 0, 1),
                 ("configs[2]: primary + shadow ray, 2 denoiser passes", 0, True, 0, 2),
                 ("reference defaults: AO 4 x 64 steps, shadow ray, <= 5 bounces, 2 denoiser passes", 4, True, 5, 2))]
+            # the same three workloads one frame per call with 1, 2 and 3 frames in flight (the reference's own pattern)
+            st_c3 = vrt.VoxelRenderSettings.primary_only((W, H)); st_c3.traceSettings.shadows = True
+            st_df = vrt.VoxelRenderSettings(targetResolution=(W, H)); st_df.fsrSetttings.enable = False
+            roofline["single_frame_launch"]["frames_in_flight"] = frames_in_flight(
+                vrt, scene, pushes[0], W, H, (("primary", st), ("config3_geometry", st_c3), ("reference_defaults_geometry", st_df)))
             # north_star's "1080p and 4K": the headline's scene and camera path at 3840x2160, primary rays only -- batched like the
             # headline (16 frames per launch: 77 MB of planes x 4 each) and one frame per launch
             extra.append(primary_4k(vrt, torch, engine, scene, NV, pos0, yaw, pitch))
