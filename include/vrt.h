@@ -357,6 +357,10 @@ int  vrt_last_timings(vrt_ctx* ctx, float* primary_ms, float* geometry_ms, float
  * out[4i+2] = 1 if the fast path is sure of its texel (only then may the two be compared), out[4i+3] = float bits of the
  * fast coordinate u * sky_w.  tests/test_gpu_sky.py sweeps it over 10^8 directions. */
 int  vrt_debug_sky_texels(vrt_ctx* ctx, const vrt_scene* scene, const float* dirs_dev, size_t n, uint32_t* out_dev);
+/* Development builds only (make variant EXTRA=-DVRT_TRACE_COUNTERS; the product library answers zeros): look-ups of the brick
+ * march since the last call, summed over the lanes of all rays -- all, those inside an occupied brick (the second, dependent
+ * load), those that found a solid voxel, those that ended in the border or an open brick.  Waits for the stream; resets. */
+int  vrt_debug_brick_counts(vrt_ctx* ctx, uint64_t out[4]);
 /* Enable/disable per-call event recording (default on). */
 int  vrt_ctx_set_timing(vrt_ctx* ctx, int enabled);
 

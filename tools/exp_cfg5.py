@@ -14,6 +14,7 @@ def flag(name, default):
     return default
 ao, sh, bo = int(flag("--ao", "4")), int(flag("--shadows", "1")), int(flag("--bounces", "4"))
 split = int(flag("--split", "0"))
+xflags = int(flag("--flags", "0"))
 eng = vrt.Engine(0)
 for a in args:
     k, v = a.split("="); eng.set_option(k, int(v))
@@ -29,6 +30,11 @@ st.fsrSetttings.enable = False
 st.occlusionSettings.numSamples = ao; st.traceSettings.shadows = bool(sh); st.traceSettings.maxReflections = bo; st.traceSettings.maxRaySteps = 6144
 st.denoiserSettings.enable = False
 st.traceSettings.splitKernels = bool(split)
+if xflags:
+    _to_c = st.to_c
+    def to_c():
+        c = _to_c(); c.flags |= xflags; return c
+    st.to_c = to_c
 geo = vrt.GeometryStage(eng, st, sc)
 eng.set_timing(True)
 t = []
@@ -37,3 +43,11 @@ for _ in range(reps + 2):
     t.append(eng.last_timings()["geometry_ms"])
 t = sorted(t[2:])
 print(f"{' '.join(args) or 'defaults'} ao={ao} shadows={sh} bounces={bo} split={split}: config 5 geometry {t[len(t) // 2]:.3f} ms (min {t[0]:.3f}), scene {sc.memory_bytes() / 1e6:.0f} MB", flush=True)
+
+import ctypes as C
+cnt = (C.c_uint64 * 4)()
+vrt._capi.check(vrt.lib().vrt_debug_brick_counts(eng.ctx, cnt))
+geo.record(push); eng.synchronize()
+vrt._capi.check(vrt.lib().vrt_debug_brick_counts(eng.ctx, cnt))
+if cnt[0]:
+    print(f"   one frame: lane look-ups {cnt[0] / 1e6:.1f} M, in occupied bricks {cnt[1] / 1e6:.1f} M ({cnt[1] / cnt[0]:.3f}), solid found {cnt[2] / 1e6:.2f} M, border / open {cnt[3] / 1e6:.2f} M", flush=True)

@@ -128,6 +128,7 @@ SYMBOLS = {
     "vrt_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "vrt_ctx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "vrt_debug_sky_texels": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "vrt_debug_brick_counts": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

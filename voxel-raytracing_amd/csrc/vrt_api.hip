@@ -1491,6 +1491,17 @@ int vrt_debug_sky_texels(vrt_ctx* c, const vrt_scene* s, const float* dirs_dev, 
     return VRT_OK;
 }
 
+int vrt_debug_brick_counts(vrt_ctx* c, uint64_t out[4])
+{
+    if (!c || !out) return fail(VRT_ERR_INVALID, "vrt_debug_brick_counts: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long v[4];
+    HIPCHK(debug_brick_counts(v));
+    for (int i = 0; i < 4; i++) out[i] = v[i];
+    return VRT_OK;
+}
+
 int vrt_last_timings(vrt_ctx* c, float* primary_ms, float* geometry_ms, float* denoise_ms)
 {
     if (!c) return fail(VRT_ERR_INVALID, "ctx is NULL");

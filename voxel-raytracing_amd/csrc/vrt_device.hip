@@ -483,6 +483,20 @@ __global__ __launch_bounds__(256) void k_debug_sky(const DevScene s, const float
     out[4 * i] = sx | (sy << 16); out[4 * i + 1] = tx | (ty << 16); out[4 * i + 2] = sure ? 1u : 0u; out[4 * i + 3] = __float_as_uint(un);
 }
 
+// development build (-DVRT_TRACE_COUNTERS): the brick march's look-up counters, read and reset
+hipError_t debug_brick_counts(unsigned long long out[4])
+{
+#if defined(VRT_TRACE_COUNTERS)
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vrt_brick_counts), 32);
+    if (e != hipSuccess) return e;
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_vrt_brick_counts), zero, 32);
+#else
+    out[0] = out[1] = out[2] = out[3] = 0ull;
+    return hipSuccess;
+#endif
+}
+
 hipError_t launch_debug_sky(const DevScene& sc, const float* v, size_t n, uint32_t* out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;

@@ -244,6 +244,7 @@ hipError_t launch_brick_fine(const uint32_t* padded, int pbx, int pby, const uin
                              uint8_t* fine, hipStream_t s);
 hipError_t launch_sky_normals(const DevScene& sc, float* table, hipStream_t s);
 hipError_t launch_sky_rgba8(const float* sky, uint32_t* sky8, size_t n, hipStream_t s);
+hipError_t debug_brick_counts(unsigned long long out[4]);
 hipError_t launch_debug_sky(const DevScene& sc, const float* v, size_t n, uint32_t* out, hipStream_t s);
 hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int mark = 0);
 hipError_t launch_tile_tags(const GeomParams& p, hipStream_t s);

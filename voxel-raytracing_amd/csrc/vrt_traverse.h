@@ -1354,6 +1354,10 @@ VRT_HD uint64_t brick_entry_pack(uint32_t ptr, const uint8_t coarse[8])
 // voxel's id where that is 0 inside an occupied brick.  One 8-byte load answers for an empty brick, the border and an open
 // brick; only a lane inside an OCCUPIED brick goes on to its per-voxel byte.  The arithmetic for the empty-brick answer runs
 // for every lane (a dozen instructions, no branch); 32-bit offsets while the padded grid is below 2^29 bricks.
+#if defined(VRT_TRACE_COUNTERS) && defined(__HIPCC__)
+// development build only: look-ups of the brick march by kind, summed over the lanes of all rays (vrt_debug_counters)
+__device__ unsigned long long g_vrt_brick_counts[4];   // lanes looking up, ... in an occupied brick, ... that found a solid voxel, ... in the border / an open brick
+#endif
 VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_t oct, int sx, int sy, int sz, uint32_t& material)
 {
     const uint32_t bx = (uint32_t)((mx >> 3) + 1), by = (uint32_t)((my >> 3) + 1), bz = (uint32_t)((mz >> 3) + 1);   // (-1 >> 3 = -1: the border brick)
@@ -1373,6 +1377,21 @@ VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_
         clear = v.bfine[(size_t)(ptr - 1u) * 4096u + (size_t)(oct * 512u + l)];
         if (clear == 0u) material = v.bpool[(size_t)(ptr - 1u) * 512u + (size_t)l];
     }
+#if defined(VRT_TRACE_COUNTERS) && defined(__HIP_DEVICE_COMPILE__)
+    {
+        const bool occb = c == 0u && ptr - 1u < 0xFFFFFEu;
+        const unsigned long long n0 = __builtin_popcountll(__ballot(true)), n1 = __builtin_popcountll(__ballot(occb)),
+                                 n2 = __builtin_popcountll(__ballot(occb && clear == 0u)), n3 = __builtin_popcountll(__ballot(!occb && clear == 0u));
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u || __ballot(true) != ~0ull) {
+            // one lane of the active set adds for all (the first active lane)
+            const unsigned long long act = __ballot(true);
+            if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(act)) {
+                atomicAdd(&g_vrt_brick_counts[0], n0); atomicAdd(&g_vrt_brick_counts[1], n1);
+                atomicAdd(&g_vrt_brick_counts[2], n2); atomicAdd(&g_vrt_brick_counts[3], n3);
+            }
+        }
+    }
+#endif
     return clear;
 }
 
