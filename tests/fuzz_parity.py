@@ -59,6 +59,11 @@ def run(cases, seed, eng, verbose=True):
       exp = oracle.render(osn, push, oracle.params_from(st.to_c()), nthreads=8)
       names = GB + DBG if trav not in ("JUMP", "DFJ") else GB + ["color_f", "hit_id", "hit_voxel", "hit_mask", "rays_total"]
       b = compare_planes(gb.numpy(), exp, names)
+      # ... and the launch a caller of the product makes: the reference's six targets and nothing else (the sky-texel fast path, no
+      # diagnostic march)
+      plain = vrt.GeometryStage(eng, st, sc).record(push)
+      eng.synchronize()
+      b += compare_planes(plain.numpy(), exp, GB)
       it = int(rng.integers(0, 4)); sw = float(rng.choice([2.0, 1.0, 1.5, 0.0, 3.0])); dmode = int(rng.integers(0, 2))
       st.denoiserSettings.iterations = it; st.denoiserSettings.stepWidth = sw; st.denoiserSettings.mode = dmode
       den = vrt.DenoiserStage(eng, st).record(gb.color, gb.normal, gb.position)
