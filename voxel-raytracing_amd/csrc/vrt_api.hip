@@ -47,6 +47,7 @@ struct DevOptions {
     int fast_loop = 1;         // AUTO / DF through the hand-written look-up loop
     int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
+    int thresh_runs = 1;       // primary rays through df_prim_loop (long runs by threshold)
     int denoise_th16 = 0;      // the tolerance denoiser on 64 x 16 tiles
     int denoise_packed = 1;    // the exact weighted pass two taps at a time in packed fp32
     int open_cells = 1;        // (scene build) open cells / open bricks in the clearance fields
@@ -58,7 +59,7 @@ static const OptName kOptNames[] = {
     {"tile_tags", "VRT_TILE_TAGS", &DevOptions::tile_tags}, {"box_rect", "VRT_BOX_RECT", &DevOptions::box_rect},
     {"xcd_regions", "VRT_XCD_REGIONS", &DevOptions::xcd_regions}, {"fast_loop", "VRT_FAST_LOOP", &DevOptions::fast_loop},
     {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
-    {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
+    {"thresh_runs", "VRT_THRESH_RUNS", &DevOptions::thresh_runs}, {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
     {"open_cells", "VRT_OPEN_CELLS", &DevOptions::open_cells}, {"df_prefetch", "VRT_DF_PREFETCH", &DevOptions::df_prefetch},
     {"df_own", "VRT_DF_OWN", &DevOptions::df_own},
 };
@@ -985,6 +986,10 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
                   !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (!sec || st->ao_samples == 0 || (st->ao_steps >= 1 && st->ao_steps <= 1024));
         for (int f = 0; f < n && ok; f++) ok = frames[f].hit_voxel == nullptr;      // the fast loop keeps no mapPos: no hit_voxel plane
         p.fast_loop = ok ? 1 : 0;
+        // ... and the primary rays' long runs by threshold (df_prim_loop): launches that report no iteration counts (the loop keeps
+        // none), axis step counts the position recovery is exact for, a budget worth not counting
+        const int dmax = s->d.vol.W > s->d.vol.H ? (s->d.vol.W > s->d.vol.D ? s->d.vol.W : s->d.vol.D) : (s->d.vol.H > s->d.vol.D ? s->d.vol.H : s->d.vol.D);
+        p.sc.vol.df_thresh = (ok && c->opt.thresh_runs && !counts && !(st->flags & VRT_FLAG_MARCHED_COUNTS) && dmax <= 1022 && st->max_steps >= 32) ? 1u : 0u;
     }
     // the sky texel of waves that cannot hit anything by vrt_sky.h: launches whose frames hold the reference's targets only
     // (a diagnostic plane wants values the short path does not make), pixel offsets that fit 32 bits, a sky the bound admits

@@ -78,6 +78,7 @@ struct VolumeView {
                                 // min(15, bricks)) -- bgrid and bcoarse folded into one load instead of two dependent ones
     uint32_t        df_own;      // 1: AO rays through df_any_loop (development switch)
     uint32_t        df_prefetch; // 1: the secondary rays' look-ups through trace_df_fast prefetch the neighbouring rows (development switch)
+    uint32_t        df_thresh;   // 1: primary rays through df_prim_loop (long runs by threshold; launches that report no iteration counts)
     uint32_t        brick_open;  // 1: bit 7 of a coarse byte (no occupied brick is left in the box between this brick and the volume's
                                 // corner in the octant's direction: a ray here is a miss) ends the march; 0: the bit is ignored   // padded grid dimensions in x and y
     int32_t W, H, D;
@@ -217,6 +218,7 @@ struct DdaState {
     int sx, sy, sz;           // rayStep
     uint32_t mask;            // rule A initial mask
     float ivx, ivy, ivz;      // 1 / dir (dda_entry -> dda_rest)
+    float tspan;              // length of the ray inside the box, from where the march starts to where it leaves (0: never inside)
 };
 
 // boxIntersection (frag:109-125) and the first mapPos (frag:135): everything needed to know whether the march can
@@ -240,6 +242,8 @@ VRT_HD void dda_entry(const VolumeView& v, f3 start, f3 dir, DdaState& s)
     }
     s.mx = (int)floorf(s.p.x); s.my = (int)floorf(s.p.y); s.mz = (int)floorf(s.p.z);
     s.ivx = ivx; s.ivy = ivy; s.ivz = ivz;
+    const float t0 = fmaxf(tmin, 0.0f);
+    s.tspan = tmax >= t0 ? tmax - t0 : 0.0f;
 }
 
 // deltaDist, rayStep, sideDist (frag:136-144)
@@ -1144,6 +1148,198 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
 #undef VRT_F_PREFETCH
 }
 
+// ---- the same march for PRIMARY rays: long runs by threshold, every lane its own clearance ------------------------------------
+// sideDist of an axis only ever grows by that axis' own additions, x (+) dx (+) dx ..., whatever the other two axes do: the three
+// axes are three independent sequences, and the shader's loop is their MERGE -- every iteration takes the smallest value (equal
+// values together, frag:164).  So "the state after every event with a value <= T has been processed" is a state the loop passes
+// through, for ANY T, and it can be reached without merging: step each axis on its own while its sideDist is <= T.  One
+// compare and one addition per STEP (v_cmpx narrows EXEC monotonically: a lane that has passed T stays out, nothing to put back
+// between steps) where the merged iteration spends seven vector and three scalar instructions on the same addition.  T is the
+// lane's own: with clearance c every position at most c - 1 steps away along each axis lies in the empty cube, and
+//     T = min over axes of (side + (c - 1) delta), times (1 - 2^-16),
+// is below the value at which any axis would take its c-th step (c - 1 <= 126 roundings of 2^-24 each cannot bridge 2^-16), so a
+// lane spends ITS OWN clearance and the wave needs no vote on the run length at all.  The position afterwards follows from the
+// sideDist travelled, as in df_fast_loop's long runs; the cell a lane lands on lies inside the cube, i.e. it is EMPTY: a solid
+// voxel is only ever found after one of the short runs (a vote of 1..4 somewhere in the wave: up to four merged iterations for
+// everybody, as before), which leave the mask bits of their last iteration behind.
+// What this loop does not know is how many ITERATIONS a lane has taken (two axes that hold the same value step in one): it has
+// no budget.  So it is entered only by waves none of whose rays can reach the budget at all (trace_df_fast): a ray takes at most
+// one step per integer plane it crosses, i.e. no more than (its length inside the box) x (|dir.x| + |dir.y| + |dir.z|) + 3
+// iterations whatever it meets; where that bound stays below maxSteps the budget is dead code, and every other wave takes
+// df_fast_loop, which counts.  A ray that finds nothing leaves through the border or an open cell as it always did.  Launches
+// that report iteration counts do not come here.
+// Hazards as in df_fast_loop.  Runs under the EXEC mask it is entered with.
+__device__ __forceinline__ void df_prim_loop(const uint8_t* base, int pw, int pwh, uint32_t sentinel,
+                                             float& x, float& y, float& z, float dx, float dy, float dz,
+                                             float gx, float gy, float gz, float cx, float cy, float cz,
+                                             uint32_t idx0, uint32_t voxoff, uint32_t& lmask, uint32_t& material,
+                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz)
+{
+#define VRT_P_EITER_IDX                                          \
+        "s_mov_b64 exec, s[68:69]\n\t"                            \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
+        "v_cmpx_eq_u32 v48, %[x]\n\t"                             \
+        "v_add_f32 %[x], %[x], %[dx]\n\t"                         \
+        "v_add_u32 v53, v53, %[ix]\n\t"                           \
+        "s_mov_b64 exec, s[68:69]\n\t"                            \
+        "v_cmpx_eq_u32 v48, %[y]\n\t"                             \
+        "v_add_f32 %[y], %[y], %[dy]\n\t"                         \
+        "v_add_u32 v53, v53, %[iy]\n\t"                           \
+        "s_mov_b64 exec, s[68:69]\n\t"                            \
+        "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
+        "v_add_f32 %[z], %[z], %[dz]\n\t"                         \
+        "v_add_u32 v53, v53, %[iz]\n\t"
+    // one axis of a threshold run: up to 128 steps, four per trip; EXEC only ever narrows, so the trip that empties it ends the axis
+#define VRT_P_AXIS(A, DA, L)                                     \
+        "s_movk_i32 s61, 31\n\t"                                  \
+        L "0:\n\t"                                                \
+        "v_cmpx_ge_f32 v54, " A "\n\t"                        \
+        "v_add_f32 " A ", " A ", " DA "\n\t"                      \
+        "v_cmpx_ge_f32 v54, " A "\n\t"                        \
+        "v_add_f32 " A ", " A ", " DA "\n\t"                      \
+        "v_cmpx_ge_f32 v54, " A "\n\t"                        \
+        "v_add_f32 " A ", " A ", " DA "\n\t"                      \
+        "v_cmpx_ge_f32 v54, " A "\n\t"                        \
+        "v_add_f32 " A ", " A ", " DA "\n\t"                      \
+        "s_cbranch_execz " L "1f\n\t"                             \
+        "s_sub_u32 s61, s61, 1\n\t"                               \
+        "s_cbranch_scc0 " L "0b\n\t"                              \
+        L "1:\n\t"                                                \
+        "s_mov_b64 exec, s[68:69]\n\t"
+    // scalars of the block: s61 = run length / trip counter, s63 = 0xFF, s[66:67] = saved EXEC, s[68:69] = EXEC on entry;
+    // vectors: v48..v50 temporaries, v52 = the byte read (the lane's clearance; 0xFF: finished), v53 = index of the byte to
+    // read next, v54 = the lane's threshold
+    asm volatile(
+        ".p2align 6\n\t"
+        "s_movk_i32 s63, 0xff\n\t"
+        "s_mov_b64 s[68:69], exec\n\t"
+        "v_mov_b32 v53, %[idx0]\n\t"
+        "s_mov_b32 s62, 0\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "10:\n\t"                                                   // ---- look-up: every lane's byte is here ----
+        // (every look-up is followed by at least one step of every live lane, and no ray has more than 3 x 1024 steps in it: the
+        // count below only ends a wave whose rays cannot step at all -- direction (0, 0, 0): the shader's loop spins to its budget
+        // and misses, and so does a lane that is still live here)
+        "s_add_u32 s62, s62, 1\n\t"
+        "s_cmp_gt_u32 s62, 0x1000\n\t"
+        "s_cbranch_scc1 40f\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "11:\n\t"
+        "v_cmp_gt_u32_e32 vcc, 2, v52\n\t"                          // 0 (solid / border / open) or 1 somewhere?
+        "s_cbranch_vccnz 15f\n\t"
+        "v_cmp_gt_u32_e32 vcc, 5, v52\n\t"                          // 2, 3 or 4 somewhere (and nothing below)?
+        "s_cbranch_vccnz 16f\n\t"
+        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t"                        // everybody has >= 5, or is finished -- anybody live at all?
+        "s_cbranch_vccz 40f\n\t"
+        // ---- a threshold run: T = min(side + (c - 1) delta) (1 - 2^-16); a finished lane (delta 0, c - 1 = 254) gets T below
+        //      every side and takes no step; an axis that cannot step has side = delta = inf and never holds the minimum ----
+        "v_add_u32 v48, -1, v52\n\t"
+        "v_cvt_f32_u32_e32 v48, v48\n\t"
+        "v_fma_f32 v49, v48, %[dx], %[x]\n\t"
+        "v_fma_f32 v50, v48, %[dy], %[y]\n\t"
+        "v_fma_f32 v48, v48, %[dz], %[z]\n\t"
+        "v_min3_f32 v49, v49, v50, v48\n\t"
+        "v_mul_f32 v54, 0x3f7fff00, v49\n\t"
+        VRT_P_AXIS("%[x]", "%[dx]", "2")
+        VRT_P_AXIS("%[y]", "%[dy]", "3")
+        VRT_P_AXIS("%[z]", "%[dz]", "5")
+        // ---- where is every lane now?  request its next byte ----
+        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"                     // (legacy: inf * 0 = 0, an axis the ray cannot step along)
+        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t"
+        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t"
+        "v_add_f32 v48, v48, %[cx]\n\t"
+        "v_add_f32 v49, v49, %[cy]\n\t"
+        "v_add_f32 v50, v50, %[cz]\n\t"
+        "v_cvt_rpi_i32_f32 v48, v48\n\t"
+        "v_cvt_rpi_i32_f32 v49, v49\n\t"
+        "v_cvt_rpi_i32_f32 v50, v50\n\t"
+        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t"
+        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t"
+        "v_add_u32 v53, %[idx0], v48\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "s_branch 10b\n\t"
+        "16:\n\t"                                                   // ---- the smallest vote is 2, 3 or 4 ----
+        "v_cmp_eq_u32_e32 vcc, 2, v52\n\t"
+        "s_mov_b32 s61, 2\n\t"
+        "s_cbranch_vccnz 18f\n\t"
+        "v_cmp_eq_u32_e32 vcc, 3, v52\n\t"
+        "s_mov_b32 s61, 3\n\t"
+        "s_cbranch_vccnz 18f\n\t"
+        "s_mov_b32 s61, 4\n\t"
+        "18:\n\t"                                                   // ---- a run of s61 in 1..4 merged iterations, index moved along ----
+        "s_cmp_eq_u32 s61, 1\n\t"
+        "s_cbranch_scc1 184f\n\t"
+        "s_cmp_eq_u32 s61, 2\n\t"
+        "s_cbranch_scc1 183f\n\t"
+        "s_cmp_eq_u32 s61, 3\n\t"
+        "s_cbranch_scc1 182f\n\t"
+        VRT_P_EITER_IDX
+        "182:\n\t"
+        VRT_P_EITER_IDX
+        "183:\n\t"
+        VRT_P_EITER_IDX
+        "184:\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
+        "v_cmpx_eq_u32 v48, %[x]\n\t"
+        "s_mov_b64 %[kx], exec\n\t"
+        "v_add_f32 %[x], %[x], %[dx]\n\t"
+        "v_add_u32 v53, v53, %[ix]\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        "v_cmpx_eq_u32 v48, %[y]\n\t"
+        "s_mov_b64 %[ky], exec\n\t"
+        "v_add_f32 %[y], %[y], %[dy]\n\t"
+        "v_add_u32 v53, v53, %[iy]\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        "v_cmpx_eq_u32 v48, %[z]\n\t"
+        "s_mov_b64 %[kz], exec\n\t"
+        "v_add_f32 %[z], %[z], %[dz]\n\t"
+        "v_add_u32 v53, v53, %[iz]\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        "global_load_ubyte v52, v53, %[base]\n\t"
+        "s_branch 10b\n\t"
+        "15:\n\t"                                                   // ---- some lane read 0 or 1 ----
+        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t"
+        "s_mov_b32 s61, 1\n\t"
+        "s_cbranch_vccz 18b\n\t"                                    // only 1s: a single-iteration run
+        "s_and_saveexec_b64 s[66:67], vcc\n\t"                      // lanes that read 0: a solid voxel, the border, or an open cell
+        "v_add_u32 v48, v53, %[voxoff]\n\t"
+        "global_load_ubyte %[mat], v48, %[base]\n\t"                // the voxel id (0 in the border and in an open cell: a miss)
+        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t"
+        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t"
+        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t"
+        "v_or3_b32 %[lm], v48, v49, v50\n\t"
+        "v_mov_b32 %[dx], 0\n\t"
+        "v_mov_b32 %[dy], 0\n\t"
+        "v_mov_b32 %[dz], 0\n\t"
+        "v_mov_b32 %[gx], 0\n\t"
+        "v_mov_b32 %[gy], 0\n\t"
+        "v_mov_b32 %[gz], 0\n\t"
+        "v_mov_b32 %[cx], 0\n\t"
+        "v_mov_b32 %[cy], 0\n\t"
+        "v_mov_b32 %[cz], 0\n\t"
+        "v_mov_b32 %[ix], 0\n\t"
+        "v_mov_b32 %[iy], 0\n\t"
+        "v_mov_b32 %[iz], 0\n\t"
+        "v_mov_b32 %[idx0], %[sent]\n\t"
+        "v_mov_b32 v53, %[sent]\n\t"
+        "v_mov_b32 v52, s63\n\t"
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "s_branch 11b\n\t"                                          // the other lanes' bytes are still to be looked at
+        "40:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
+          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
+          [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material),
+          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz)
+        : [voxoff] "v"(voxoff), [base] "s"(base), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54",
+          "s61", "s62", "s63", "s66", "s67", "s68", "s69");
+#undef VRT_P_AXIS
+#undef VRT_P_EITER_IDX
+}
+
 // ---- the same march for rays that point every way (AO): every lane spends ITS OWN clearance -------------------------------
 // The lanes of a primary or a shadow wave are neighbours going the same way, and the wave-wide minimum of their clearances
 // costs little.  The AO rays of a wave point every way from a surface: somebody's cube is always tiny, the minimum is 1 or 2, and
@@ -1302,7 +1498,18 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     const uint64_t b64 = (uint64_t)v.df - (uint64_t)bias;
     const uint8_t* base = (const uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));      // (the builtin returns int)
-    if (ANYHIT && OWN && __builtin_amdgcn_readfirstlane((int)v.df_own) != 0) {
+    // primary rays: the loop without a budget (df_prim_loop) for a wave none of whose rays can take maxSteps iterations: a ray
+    // steps once per integer plane it crosses, at most tspan * (|dir.x| + |dir.y| + |dir.z|) + 3 times (the margin below covers the
+    // rounding of the three factors and the march's own deviation from the ideal line)
+    bool thresh = false;
+    if (!ANYHIT && !PF && __builtin_amdgcn_readfirstlane((int)v.df_thresh) != 0) {
+        const float bound = s.tspan * ((fabsf(dir.x) + fabsf(dir.y)) + fabsf(dir.z)) * 1.001f + 8.0f;
+        thresh = __ballot(!done0 && !(bound < (float)maxSteps)) == 0ull;
+    }
+    if (thresh) {
+        df_prim_loop(base, __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh), (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel),
+                     x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, kx, ky, kz, incx, incy, incz);
+    } else if (ANYHIT && OWN && __builtin_amdgcn_readfirstlane((int)v.df_own) != 0) {
         df_any_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
                     (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, material, fetches,
                     (uint32_t)__builtin_amdgcn_readfirstlane((int)v.count_marched));
