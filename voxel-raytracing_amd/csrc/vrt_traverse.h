@@ -1498,11 +1498,11 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     const uint64_t b64 = (uint64_t)v.df - (uint64_t)bias;
     const uint8_t* base = (const uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));      // (the builtin returns int)
-    // primary rays: the loop without a budget (df_prim_loop) for a wave none of whose rays can take maxSteps iterations: a ray
+    // the loop without a budget (df_prim_loop) for a wave none of whose rays can take maxSteps iterations: a ray
     // steps once per integer plane it crosses, at most tspan * (|dir.x| + |dir.y| + |dir.z|) + 3 times (the margin below covers the
     // rounding of the three factors and the march's own deviation from the ideal line)
     bool thresh = false;
-    if (!ANYHIT && !PF && __builtin_amdgcn_readfirstlane((int)v.df_thresh) != 0) {
+    if (!OWN && __builtin_amdgcn_readfirstlane((int)v.df_thresh) != 0) {      // (primary, bounce and shadow rays; the AO rays' 64 iterations ARE their budget)
         const float bound = s.tspan * ((fabsf(dir.x) + fabsf(dir.y)) + fabsf(dir.z)) * 1.001f + 8.0f;
         thresh = __ballot(!done0 && !(bound < (float)maxSteps)) == 0ull;
     }
