@@ -25,7 +25,7 @@ BUDGET = {
     "k_primaryILi7ELb0ELi4ELb1ELi2EE": ("megakernel without its bounce loop, table", 72, 96, 0),
     "k_primaryILi7ELb0ELi2ELb0ELi0EE": ("megakernel, one frame per launch (7 waves per SIMD by design)", 72, 96, 512),
     "k_primaryILi7ELb0ELi2ELb1ELi2EE": ("megakernel, table", 72, 96, 512),
-    "k_primaryILi6ELb0ELi2ELb0ELi0EE": ("megakernel over bricks (config 5), one frame per launch", 80, 96, 480),
+    "k_primaryILi6ELb0ELi2ELb0ELi0EE": ("megakernel over bricks (config 5), one frame per launch", 80, 96, 576),
     "k_denoise_ldsILb0ELb0ELb0ELb1EE": ("K3 weighted pass, exact, packed", 128, 96, 0),
 }
 

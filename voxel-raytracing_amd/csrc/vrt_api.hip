@@ -990,6 +990,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         // none), axis step counts the position recovery is exact for, a budget worth not counting
         const int dmax = s->d.vol.W > s->d.vol.H ? (s->d.vol.W > s->d.vol.D ? s->d.vol.W : s->d.vol.D) : (s->d.vol.H > s->d.vol.D ? s->d.vol.H : s->d.vol.D);
         p.sc.vol.df_thresh = (ok && c->opt.thresh_runs && !counts && !(st->flags & VRT_FLAG_MARCHED_COUNTS) && dmax <= 1022 && st->max_steps >= 32) ? 1u : 0u;
+        // (brick scenes: the generic loop's form of the same, brick_march_thresh; its positions come from per-run differences)
+        if (s->bricks) p.sc.vol.df_thresh = (c->opt.thresh_runs && !counts && !(st->flags & (VRT_FLAG_MARCHED_COUNTS | VRT_FLAG_DEBUG_PLANES | 2u)) && st->max_steps >= 32) ? 1u : 0u;
     }
     // the sky texel of waves that cannot hit anything by vrt_sky.h: launches whose frames hold the reference's targets only
     // (a diagnostic plane wants values the short path does not make), pixel offsets that fit 32 bits, a sky the bound admits

@@ -1353,6 +1353,9 @@ __device__ __forceinline__ void df_prim_loop(const uint8_t* base, int pw, int pw
 #ifndef VRT_OWN_CAP
 #define VRT_OWN_CAP 4                // iterations of its own a lane may take per look (df_any_loop; measured: DESIGN.md 5)
 #endif
+#ifndef VRT_THRESH_SPREAD
+#define VRT_THRESH_SPREAD 1          // brick_march_thresh: a lane's threshold run uses at most this many times the wave's smallest clearance (measured on config 5: 1 -> 3.38 ms, 2 -> 3.46, 4 -> 3.48, no cap -> 13 ms: the others wait for the lane that goes furthest)
+#endif
 #ifndef VRT_OWN_CAP_BRICK
 #define VRT_OWN_CAP_BRICK 8          // ... in the brick march, whose look-ups cost more (trace_brick_own: 5.07 ms at 4, 5.00 at 8)
 #endif
@@ -1602,6 +1605,89 @@ VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_
     return clear;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// One axis of a threshold run under the EXEC mask it is entered with: x (+)= dx while x <= T, at most 128 times (v_cmpx narrows
+// EXEC monotonically -- a lane that has passed T stays out -- so nothing is put back between steps; four steps per trip)
+__device__ __forceinline__ void axis_run(float& x, float dx, float T)
+{
+    uint64_t saved;
+    uint32_t cnt;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_movk_i32 %[cnt], 31\n\t"
+                 "1:\n\t"
+                 "v_cmpx_ge_f32 %[T], %[x]\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "v_cmpx_ge_f32 %[T], %[x]\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "v_cmpx_ge_f32 %[T], %[x]\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "v_cmpx_ge_f32 %[T], %[x]\n\t"
+                 "v_add_f32 %[x], %[x], %[dx]\n\t"
+                 "s_cbranch_execz 2f\n\t"
+                 "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                 "s_cbranch_scc0 1b\n\t"
+                 "2:\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [x] "+v"(x), [sv] "=&s"(saved), [cnt] "=&s"(cnt)
+                 : [dx] "v"(dx), [T] "v"(T)
+                 : "vcc", "scc");
+}
+
+// The brick march without a budget, its long runs by threshold (df_prim_loop's scheme in the generic loop): a run of up to four
+// iterations for everybody when some lane's clearance is that small (they leave the mask bits behind that a hit needs), else
+// every lane steps each axis on its own while its sideDist is <= the lane's threshold min(side + (c - 1) delta) (1 - 2^-16) --
+// one compare and one addition per step, every lane its own clearance.  Entered only by waves none of whose rays can take
+// maxSteps iterations (trace_brick); primary, bounce and shadow rays.
+template <class STATS>
+__device__ __forceinline__ void brick_march_thresh(const VolumeView& v, DdaState& s, f3 dir, RayInt& r, STATS& stats)
+{
+    asm volatile("" : "+v"(s.dx), "+v"(s.dy), "+v"(s.dz));
+    uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
+    uint32_t lmask = s.mask, material = 0u, clear = 63u;
+    bool done = oob(v, s.mx, s.my, s.mz);
+    const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
+    const float kInf = u2f(0x7F800000u);
+    const float gx = s.dx < kInf ? dir.x : 0.0f, gy = s.dy < kInf ? dir.y : 0.0f, gz = s.dz < kInf ? dir.z : 0.0f;
+    // (every look-up is followed by at least one step of every live lane: the count only ends a wave whose rays cannot step --
+    // direction (0, 0, 0): the shader's loop spins to its budget and misses, and so does a lane still live here)
+    for (uint32_t guard = 0; guard < 16384u; guard++) {
+        if (!done) {
+            uint32_t m = 0u;
+            clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m);
+            st_lookup(stats);
+            if (clear == 0u) {                                 // solid, the border, or an open brick
+                if (!oob(v, s.mx, s.my, s.mz)) material = m;
+                done = true;
+                lmask = lane_bits(kx, ky, kz);
+            }
+        }
+        uint32_t vote = done ? VRT_VOTE_DONE : clear;
+        asm volatile("" : "+v"(vote));
+        if (__ballot(vote != VRT_VOTE_DONE) == 0ull) break;
+        const float ox = s.sdx, oy = s.sdy, oz = s.sdz;
+        if (__ballot(vote < 5u) != 0ull) {
+            // a short run for everybody: the smallest clearance, 1..4 iterations, the last one's EXEC masks are the mask bits
+            const uint32_t kw = wave_min_vote(vote);
+            const uint64_t live = __ballot(vote != VRT_VOTE_DONE);
+            float qx, qy, qz;
+            dda_run_live_masks(s, live, kw, kx, ky, kz, qx, qy, qz);
+        } else {
+            // (a lane's own clearance, but no more than VRT_THRESH_SPREAD times the smallest of the wave: the others wait for the
+            // lane that goes furthest; a finished lane has T = -1: it takes no step)
+            const uint32_t kmin = wave_min_vote(vote), cap = kmin * (uint32_t)VRT_THRESH_SPREAD;
+            const float cm1 = (float)((clear < cap ? clear : cap) - 1u);
+            float T = fminf(fminf(__builtin_fmaf(cm1, s.dx, s.sdx), __builtin_fmaf(cm1, s.dy, s.sdy)), __builtin_fmaf(cm1, s.dz, s.sdz)) * 0.99998474f;
+            if (done) T = -1.0f;
+            axis_run(s.sdx, s.dx, T);
+            axis_run(s.sdy, s.dy, T);
+            axis_run(s.sdz, s.dz, T);
+        }
+        s.mx += steps_signed(s.sdx - ox, gx); s.my += steps_signed(s.sdy - oy, gy); s.mz += steps_signed(s.sdz - oz, gz);
+    }
+    finish(s, material, lmask, 0u, r);
+}
+#endif
+
 template <class STATS, bool ANYHIT = false>
 VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
@@ -1615,6 +1701,14 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
     }
     dda_rest(dir, s);
 #if defined(__HIP_DEVICE_COMPILE__)
+    // the march without a budget for a wave none of whose rays can take maxSteps iterations (the bound of trace_df_fast)
+    if (__builtin_amdgcn_readfirstlane((int)v.df_thresh) != 0) {
+        const float bound = s.tspan * ((fabsf(dir.x) + fabsf(dir.y)) + fabsf(dir.z)) * 1.001f + 8.0f;
+        if (__ballot(!oob(v, s.mx, s.my, s.mz) && !(bound < (float)maxSteps)) == 0ull) {
+            brick_march_thresh(v, s, dir, r, stats);
+            return;
+        }
+    }
     asm volatile("" : "+v"(s.dx), "+v"(s.dy), "+v"(s.dz));
     uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
     uint32_t lmask = s.mask;
