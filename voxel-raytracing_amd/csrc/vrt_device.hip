@@ -925,7 +925,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     // the tile map arrives with one 64-byte scalar load (and one wait) before anything depends on it
     TileMap M = P.map;
+#ifdef VRT_EXP_STAMPS
+    const uint64_t t_begin = wall_clock64();                                 // (development build, tools/exp_timeline2.py: every wave's start / end stamp goes to the motion plane)
+#else
     const uint64_t t_begin = (M.flags & 2u) ? wall_clock64() : 0ull;         // diagnostic timeline (100 MHz)
+#endif
     int x0, y0, yp0, ty, tx;
     uint32_t frame;
     if (!block_to_tile<MAP>(M, frame, ty, tx)) return;                   // uniform per workgroup
@@ -1017,7 +1021,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             const uint32_t c8 = *gptr<const uint32_t>(sky8, (ty * k.w + tx) << 2);
             const uint32_t i32 = (uint32_t)py * (uint32_t)W + (uint32_t)px;
             if (f.position) *gptr<vrt_f4>(f.position, i32 << 4) = (vrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef VRT_EXP_STAMPS
+            if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){__uint_as_float((uint32_t)t_begin), __uint_as_float((uint32_t)wall_clock64())};
+#else
             if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){0.0f, 0.0f};
+#endif
             if (f.depth) *gptr<float>(f.depth, i32 << 2) = 0.0f;
             if (f.normal8) *gptr<uint32_t>(f.normal8, i32 << 2) = 0u;
             if (f.mask8) *gptr<uint8_t>(f.mask8, i32) = (uint8_t)0;
@@ -1048,7 +1056,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // 2^28 pixels)
     const uint32_t i32 = (uint32_t)i;
     if (f.depth) *gptr<float>(f.depth, i32 << 2) = depth;
+#ifndef VRT_EXP_STAMPS
     if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){0.0f, 0.0f};
+#endif
     if (f.mask8) *gptr<uint8_t>(f.mask8, i32) = hit ? (uint8_t)230 : (uint8_t)0;          // unorm8(0.9f) = 230 (tests/test_oracle_kat.py), unorm8(0) = 0
     if (f.position) *gptr<vrt_f4>(f.position, i32 << 4) = (vrt_f4){h.pos.x, h.pos.y, h.pos.z, 0.0f};
     if (f.normal8) {
@@ -1086,6 +1096,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             col = sky_color(s, dir);
         }
         store_color(f, col, i, i32, ((uint32_t)(yp0 + (py - y0)) * (uint32_t)W + (uint32_t)px) << 2);
+#ifdef VRT_EXP_STAMPS
+        if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){__uint_as_float((uint32_t)t_begin), __uint_as_float((uint32_t)wall_clock64())};
+#endif
     } else if (hit) {
         // hit record for K2 (position bits + material | mask << 8 | (step+1) codes) and a slot in the compacted list of
         // hit pixels: K2 then runs one lane per HIT pixel instead of one per pixel (hipcc folds the per-lane
