@@ -64,6 +64,19 @@ def run(cases, seed, eng, verbose=True):
       plain = vrt.GeometryStage(eng, st, sc).record(push)
       eng.synchronize()
       b += compare_planes(plain.numpy(), exp, GB)
+      # ... and the same content as a brick scene (8^3 bricks; volumes whose sides are multiples of 8): the brick march and its
+      # threshold runs (AUTO is the one traversal a brick scene renders with; the split form has no brick kernel of its own)
+      if W % 8 == 0 and H % 8 == 0 and D % 8 == 0 and not st.traceSettings.splitKernels:
+          grid, pool = vrt.synthetic.bricks_from_dense(vol)
+          sb = vrt.VoxelScene.from_bricks(eng, grid, pool, pal, sky=sky, noise=noise)
+          trav0 = st.traceSettings.traversal
+          st.traceSettings.traversal = vrt.TRAVERSAL_AUTO
+          expb = exp if trav in ("DF", "DENSE", "BITMASK") else oracle.render(osn, push, oracle.params_from(st.to_c()), planes=GB, nthreads=8)
+          pb = vrt.GeometryStage(eng, st, sb).record(push)
+          eng.synchronize()
+          b += compare_planes(pb.numpy(), expb, GB)
+          st.traceSettings.traversal = trav0
+          sb.destroy()
       it = int(rng.integers(0, 4)); sw = float(rng.choice([2.0, 1.0, 1.5, 0.0, 3.0])); dmode = int(rng.integers(0, 2))
       st.denoiserSettings.iterations = it; st.denoiserSettings.stepWidth = sw; st.denoiserSettings.mode = dmode
       den = vrt.DenoiserStage(eng, st).record(gb.color, gb.normal, gb.position)
