@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -48,6 +49,7 @@ struct DevOptions {
     int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
     int thresh_runs = 1;       // primary rays through df_prim_loop (long runs by threshold)
+    int hit_table = 1;         // launches without secondary rays take a hit's colour from the table of colorHit() over materials x normals
     int denoise_th16 = 0;      // the tolerance denoiser on 64 x 16 tiles
     int denoise_packed = 1;    // the exact weighted pass two taps at a time in packed fp32
     int open_cells = 1;        // (scene build) open cells / open bricks in the clearance fields
@@ -59,6 +61,7 @@ static const OptName kOptNames[] = {
     {"tile_tags", "VRT_TILE_TAGS", &DevOptions::tile_tags}, {"box_rect", "VRT_BOX_RECT", &DevOptions::box_rect},
     {"xcd_regions", "VRT_XCD_REGIONS", &DevOptions::xcd_regions}, {"fast_loop", "VRT_FAST_LOOP", &DevOptions::fast_loop},
     {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
+    {"hit_table", "VRT_HIT_TABLE", &DevOptions::hit_table},
     {"thresh_runs", "VRT_THRESH_RUNS", &DevOptions::thresh_runs}, {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
     {"open_cells", "VRT_OPEN_CELLS", &DevOptions::open_cells}, {"df_prefetch", "VRT_DF_PREFETCH", &DevOptions::df_prefetch},
     {"df_own", "VRT_DF_OWN", &DevOptions::df_own},
@@ -91,6 +94,10 @@ struct vrt_ctx {
     uint32_t* tile_tags = nullptr;
     size_t tile_tags_words = 0;
     uint32_t tile_gen = 0;
+    // colorHit() over materials x normals for launches without secondary rays (k_hit_colors), and what it was made from
+    uint32_t* hit_colors = nullptr;
+    uint64_t hit_scene_gen = 0;
+    vrt_settings hit_settings{};
 };
 
 struct vrt_scene {
@@ -121,7 +128,9 @@ struct vrt_scene {
     uint64_t* bentry = nullptr;        // bgrid + bcoarse folded into one word per brick (what the march reads; the two are freed after the build)
     bool bricks = false;
     uint64_t bytes = 0;                // device memory held (volume structures + textures)
+    uint64_t shade_gen = 0;            // changes whenever something a hit's colour depends on does (creation, vrt_scene_set_sky)
 };
+static std::atomic<uint64_t> g_shade_gen{0};
 
 extern "C" {
 
@@ -158,6 +167,7 @@ void vrt_ctx_destroy(vrt_ctx* c)
     if (c->records) hipFree(c->records);
     if (c->hit_list) hipFree(c->hit_list);
     if (c->tile_tags) hipFree(c->tile_tags);
+    if (c->hit_colors) hipFree(c->hit_colors);
     if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
     for (int i = 0; i < vrt_ctx::kTabRing; i++) {
         if (c->tab_dev[i]) hipFree(c->tab_dev[i]);
@@ -311,6 +321,7 @@ int vrt_scene_set_sky(vrt_ctx* c, vrt_scene* s, const float* rgba, uint32_t w, u
     s->sky = d; s->d.sky = d; s->d.sky_w = w; s->d.sky_h = h;
     // the sky as the colour target stores a miss, and the constants of the texel fast path (vrt_sky.h)
     s->sky8 = d8; s->d.sky8 = d8; s->d.skyk = sky_fast_consts(w, h);
+    s->shade_gen = ++g_shade_gen;
     HIPCHK(launch_sky_rgba8(d, d8, (size_t)w * h, c->stream));
     // skyColor of the normals a hit can have (calcAmbient's sky tint, frag:224): 64 x float4, by the shading code itself
     if (!s->sky_normals) HIPCHK(hipMalloc((void**)&s->sky_normals, 64 * 4 * sizeof(float)));
@@ -403,6 +414,7 @@ int vrt_scene_from_dense(vrt_ctx* c, const uint8_t* voxels, uint32_t W, uint32_t
         return fail(VRT_ERR_UNSUPPORTED, "vrt_scene_from_dense: each dimension must be in 1..4096");
     HIPCHK(hipSetDevice(c->device));
     vrt_scene* s = new vrt_scene();
+    s->shade_gen = ++g_shade_gen;
     VolumeView& d = s->d.vol;
     d.W = (int)W; d.H = (int)H; d.D = (int)D;
     d.n1x = ceil_div(d.W, 4); d.n1y = ceil_div(d.H, 4); d.n1z = ceil_div(d.D, 4);
@@ -525,6 +537,7 @@ int vrt_scene_from_bricks(vrt_ctx* c, const uint32_t* grid, uint32_t nbx, uint32
         if (coord[i] == 0xFFFFFFFFu) return fail(VRT_ERR_INVALID, "vrt_scene_from_bricks: a pool brick is not referenced by the grid");
     HIPCHK(hipSetDevice(c->device));
     vrt_scene* s = new vrt_scene();
+    s->shade_gen = ++g_shade_gen;
     s->bricks = true;
     VolumeView& d = s->d.vol;
     d.W = (int)(nbx * 8u); d.H = (int)(nby * 8u); d.D = (int)(nbz * 8u);
@@ -1034,6 +1047,16 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         HIPCHK(hipStreamWaitEvent(c->stream, c->tab_uploaded[tab], 0));
     }
     if (c->timing) HIPCHK(hipEventRecord(c->ev_geo0, c->stream));
+    // primary rays only, the reference's targets only: the hits' colours from the table (made anew when the settings or the
+    // scene's sky have changed since it was made)
+    if (p.fused_shade == 1 && c->opt.hit_table && p.sky_fast) {
+        if (!c->hit_colors) { HIPCHK(hipMalloc((void**)&c->hit_colors, 256 * 64 * sizeof(uint32_t))); c->hit_scene_gen = 0; }
+        if (c->hit_scene_gen != s->shade_gen || memcmp(&c->hit_settings, st, sizeof *st) != 0) {
+            HIPCHK(launch_hit_colors(p, c->hit_colors, c->stream));
+            c->hit_scene_gen = s->shade_gen; c->hit_settings = *st;
+        }
+        p.hit_colors = c->hit_colors;
+    }
     // tile tags: dense scenes, frames with a box rectangle, launches that do not report the reference's iteration counts
     {
         bool want = c->opt.tile_tags != 0 && s->cells_ok && !counts && W <= 8128 && H <= 8128;

@@ -904,6 +904,31 @@ template <> __device__ __forceinline__ OccT<true> stage_occ<true>(const GeomPara
 // K1: primary rays
 // ---------------------------------------------------------------------------------------------
 
+// colorHit() of every (material, normal) a primary ray can hit, for launches without secondary rays (GeomParams::hit_colors)
+__global__ __launch_bounds__(256) void k_hit_colors(const GeomParams P, uint32_t* table)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t code = t & 63u, material = t >> 6, mask = code & 7u;
+    const int sx = (code & 8u) ? -1 : 1, sy = (code & 16u) ? -1 : 1, sz = (code & 32u) ? -1 : 1;
+    uint32_t c8 = 0u;
+    if (mask != 0u && material != 0u && material < 256u) {
+        RayHit h;
+        h.material = material; h.pos = mk3(0.0f, 0.0f, 0.0f); h.dir = mk3(0.0f, 0.0f, 0.0f);
+        h.normal = hit_normal(mask, sx, sy, sz); h.ncode = code;
+        PixCtx c; c.px = 0; c.py = 0; c.fetches = 0; c.rays = 0; c.pc = nullptr; c.have_noise = false;
+        OccT<false> occ; occ.o2 = nullptr; occ.o3 = nullptr;
+        const f3 col = color_hit<VRT_TRAVERSAL_DF_FAST, OccT<false>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);
+        c8 = (uint32_t)unorm8(col.x) | ((uint32_t)unorm8(col.y) << 8) | ((uint32_t)unorm8(col.z) << 16);
+    }
+    if (t < 256u * 64u) table[t] = c8;
+}
+
+hipError_t launch_hit_colors(const GeomParams& p, uint32_t* table, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hit_colors, dim3(64), dim3(256), 0, s, p, table);
+    return hipGetLastError();
+}
+
 // the pixel's colour into color_f (debug), color8 and the packed strips
 __device__ __forceinline__ void store_color(const vrt_frame& f, f3 col, size_t i, uint32_t i32, uint32_t strip_off)
 {
@@ -1082,6 +1107,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     uint32_t* const steps_total = f.steps_total; uint32_t* const rays_total = f.rays_total;
 
+    // primary rays only: a hit's colour is an entry of the launch's table (GeomParams::hit_colors: colorHit() of every material
+    // and normal, made by colorHit() itself); a wave one of whose hits has none of the 26 normals computes as before
+    if (MODE == 1) {
+        const uint32_t* const hc = P.hit_colors;
+        if (hc && !f.color_f && __ballot(hit && h.ncode == 0xFFFFFFFFu) == 0ull) {
+            uint32_t c8;
+            if (hit) c8 = *gptr<const uint32_t>(hc, ((h.material << 6) | h.ncode) << 2);
+            else {
+                const f3 col = sky_color(s, dir);
+                c8 = (uint32_t)unorm8(col.x) | ((uint32_t)unorm8(col.y) << 8) | ((uint32_t)unorm8(col.z) << 16);
+            }
+            if (f.color8) *gptr<uint32_t>(f.color8, i32 << 2) = c8;
+            if (f.color8_strips) *gptr<uint32_t>(f.color8_strips, ((uint32_t)(yp0 + (py - y0)) * (uint32_t)W + (uint32_t)px) << 2) = c8;
+            return;
+        }
+    }
     if (MODE != 0) {                                           // 1: primary only; 2: megakernel; 4: megakernel, nothing can bounce
         f3 col;
         if (hit) {

@@ -194,6 +194,11 @@ struct GeomParams {
     uint32_t   tile_gen, tags_x, tags_y, tags_per_frame;
     const uint32_t* cells;     // the scene's occupied cells (4^3 voxels; 8^3 = the bricks of a brick scene), x | y << 10 | z << 20
     uint32_t   n_cells, cell_size;
+    // Primary rays only (fused_shade == 1: ambient = 1, nothing shadowed, no reflection): the colour of a hit is a function of
+    // its material and of which of the 26 normals it has -- colorHit() for all 256 x 64 of them, made by colorHit() itself
+    // (k_hit_colors) whenever the settings or the scene's sky change, as the RGBA8 the colour target stores:
+    // hit_colors[material << 6 | ncode].  nullptr: every pixel computes its own.
+    const uint32_t* hit_colors;
 };
 
 struct DenoiseParams {
@@ -248,6 +253,7 @@ hipError_t debug_brick_counts(unsigned long long out[4]);
 hipError_t launch_debug_sky(const DevScene& sc, const float* v, size_t n, uint32_t* out, hipStream_t s);
 hipError_t launch_open_cells(const uint8_t* vox, int W, int H, int D, uint8_t* df, size_t stride, uint8_t* tmp0, uint8_t* tmp1, hipStream_t s, int mark = 0);
 hipError_t launch_tile_tags(const GeomParams& p, hipStream_t s);
+hipError_t launch_hit_colors(const GeomParams& p, uint32_t* table, hipStream_t s);
 hipError_t launch_pad_vox(const uint8_t* vox, int W, int H, int D, uint8_t* dst, hipStream_t s);
 hipError_t launch_primary(const GeomParams& p, hipStream_t s);
 hipError_t launch_shade(const GeomParams& p, hipStream_t s);
