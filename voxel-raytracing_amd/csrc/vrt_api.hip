@@ -1035,7 +1035,11 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     if (p.total_tiles == 0) return VRT_OK;
     {
         TileMap& m = p.map;
-        m.flags = (st->flags & 0xFFFFu) | (p.sky_fast ? VRT_MAPFLAG_SKY_FAST : 0u); m.n_frames = p.n_frames; m.xcd_turn = p.xcd_turn;
+        bool six = p.sky_fast != 0;                                    // (sky_fast: no diagnostic plane, no color_f)
+        for (int f = 0; f < n && six; f++)
+            six = frames[f].color8 && frames[f].depth && frames[f].motion && frames[f].mask8 && frames[f].position && frames[f].normal8 &&
+                  !frames[f].hit_id && !frames[f].color8_strips;
+        m.flags = (st->flags & 0xFFFFu) | (p.sky_fast ? VRT_MAPFLAG_SKY_FAST : 0u) | (six ? VRT_MAPFLAG_SIX : 0u); m.n_frames = p.n_frames; m.xcd_turn = p.xcd_turn;
         m.wgs_per_frame = p.wgs_per_frame; m.wgs_per_frame_rcp = p.wgs_per_frame_rcp;
         m.tiles_x = p.tiles_x; m.tiles_x_rcp = p.tiles_x_rcp; m.tiles_y_local = p.tiles_y_local; m.tiles_y_rcp = p.tiles_y_rcp;
         m.tps = p.tps; m.tps_rcp = p.tps_rcp; m.tile = p.tile_h; m.nranks = p.sh.nranks; m.strip_rows = p.sh.strip_rows;

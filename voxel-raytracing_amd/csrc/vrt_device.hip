@@ -1045,6 +1045,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             // access below is a flat instruction with a 64-bit address in two vector registers)
             const uint32_t c8 = *gptr<const uint32_t>(sky8, (ty * k.w + tx) << 2);
             const uint32_t i32 = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+#ifndef VRT_EXP_STAMPS
+            if (M.flags & VRT_MAPFLAG_SIX) {                       // the reference's six targets and nothing else: six stores, no pointer tested
+                *gptr<vrt_f4>(f.position, i32 << 4) = (vrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+                *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){0.0f, 0.0f};
+                *gptr<float>(f.depth, i32 << 2) = 0.0f;
+                *gptr<uint32_t>(f.normal8, i32 << 2) = 0u;
+                *gptr<uint8_t>(f.mask8, i32) = (uint8_t)0;
+                *gptr<uint32_t>(f.color8, i32 << 2) = c8;
+                return;
+            }
+#endif
             if (f.position) *gptr<vrt_f4>(f.position, i32 << 4) = (vrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
 #ifdef VRT_EXP_STAMPS
             if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){__uint_as_float((uint32_t)t_begin), __uint_as_float((uint32_t)wall_clock64())};
@@ -1080,6 +1091,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // them from words and would otherwise get flat instructions with a 64-bit address each; the host admits frames below
     // 2^28 pixels)
     const uint32_t i32 = (uint32_t)i;
+#ifndef VRT_EXP_STAMPS
+    // (the launch's flags once more from the kernel's own arguments: a scalar register held across the march would be the 77th)
+    const bool six = (kernarg_words(offsetof(GeomParams, map) + offsetof(TileMap, flags))[0] & VRT_MAPFLAG_SIX) != 0u;
+#else
+    const bool six = false;
+#endif
+    if (six) {                                                  // the reference's six targets and nothing else (the colour below)
+        uint32_t n = 0u;
+        if (hit) n = (uint32_t)(uint8_t)snorm8(h.normal.x) | ((uint32_t)(uint8_t)snorm8(h.normal.y) << 8) | ((uint32_t)(uint8_t)snorm8(h.normal.z) << 16);
+        *gptr<float>(f.depth, i32 << 2) = depth;
+        *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){0.0f, 0.0f};
+        *gptr<uint8_t>(f.mask8, i32) = hit ? (uint8_t)230 : (uint8_t)0;
+        *gptr<vrt_f4>(f.position, i32 << 4) = (vrt_f4){h.pos.x, h.pos.y, h.pos.z, 0.0f};
+        *gptr<uint32_t>(f.normal8, i32 << 2) = n;
+    } else {
     if (f.depth) *gptr<float>(f.depth, i32 << 2) = depth;
 #ifndef VRT_EXP_STAMPS
     if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){0.0f, 0.0f};
@@ -1105,7 +1131,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         f.steps_total[i] = (uint32_t)t_begin;
         f.rays_total[i] = (uint32_t)wall_clock64();
     }
-    uint32_t* const steps_total = f.steps_total; uint32_t* const rays_total = f.rays_total;
+    }
+    uint32_t* const steps_total = six ? nullptr : f.steps_total; uint32_t* const rays_total = six ? nullptr : f.rays_total;
 
     // primary rays only: a hit's colour is an entry of the launch's table (GeomParams::hit_colors: colorHit() of every material
     // and normal, made by colorHit() itself); a wave one of whose hits has none of the 26 normals computes as before
@@ -1118,6 +1145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                 const f3 col = sky_color(s, dir);
                 c8 = (uint32_t)unorm8(col.x) | ((uint32_t)unorm8(col.y) << 8) | ((uint32_t)unorm8(col.z) << 16);
             }
+            if (six) { *gptr<uint32_t>(f.color8, i32 << 2) = c8; return; }
             if (f.color8) *gptr<uint32_t>(f.color8, i32 << 2) = c8;
             if (f.color8_strips) *gptr<uint32_t>(f.color8_strips, ((uint32_t)(yp0 + (py - y0)) * (uint32_t)W + (uint32_t)px) << 2) = c8;
             return;

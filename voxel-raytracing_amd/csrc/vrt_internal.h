@@ -142,6 +142,8 @@ static_assert(sizeof(FrameSlot) == 256, "FrameSlot is sized for aligned scalar l
 // Everything a workgroup needs to find its tile, in one 64-byte block of the kernel arguments: a wave fetches it with one
 // scalar load and one wait instead of ten loads of one or two dwords, each waited for before the next could be issued.
 #define VRT_MAPFLAG_SKY_FAST 0x10000u   // TileMap::flags: GeomParams::sky_fast, where the wave finds it without a load of its own
+#define VRT_MAPFLAG_SIX      0x20000u   // every frame of the launch holds exactly the reference's six targets (color8, depth, motion, mask8,
+                                        // position, normal8; geometry_stage.hpp:19-27): the stores need no test of their pointers
 struct alignas(64) TileMap {
     uint32_t flags;                    // vrt_settings.flags (low 16 bits) | VRT_MAPFLAG_*
     int32_t  n_frames, xcd_turn;
