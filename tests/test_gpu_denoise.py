@@ -115,3 +115,90 @@ def test_fast_denoise_single_weighted_pass_bound(vrt, oracle, engine):
             fast = vrt.DenoiserStage(engine, st).record(c, n, p).cpu().numpy()
             exact = oracle.denoise(color, normal, position, iterations=2, mode=mode)
             assert np.abs(fast.astype(np.int32) - exact.astype(np.int32)).max() <= 1, mode
+
+
+# ---- the verified pass: exact output from a cheap evaluation + a literal one where the cheap one cannot vouch ----------------
+# (csrc/vrt_denoise_bound.h).  The default for whole-frame weighted passes with an integral tap offset; "denoise_verified" = 0 has
+# the exact kernels compute every pixel.
+
+def _hostile_gbuffer(rng, W, H):
+    """Random codes in every channel (alpha and w included, SNORM -128 too), positions clustered so that the weights are
+    neither 0 nor 1, a sprinkling of equal neighbours, huge, infinite and NaN positions."""
+    color = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    flat = rng.random((H, W, 1)) < 0.3
+    color = np.where(flat, color // 64 * 64, color).astype(np.uint8)             # flat patches: sums whose mean is a code exactly
+    nrm = rng.choice(np.array([-128, -127, -90, -73, -1, 0, 1, 73, 90, 127], np.int8), (H, W, 4))
+    nrm = np.where(rng.random((H, W, 1)) < 0.5, np.array([0, 127, 0, 0], np.int8), nrm).astype(np.int8)
+    pos = rng.uniform(0, 64, (H, W, 4)).astype(np.float32)
+    pos = (np.round(pos * 4) / 4 + rng.normal(0, 0.05, (H, W, 4))).astype(np.float32)
+    pos[..., 3] = np.where(rng.random((H, W)) < 0.9, 0.0, pos[..., 3])
+    odd = rng.random((H, W))
+    pos[odd < 0.002] = np.float32(np.nan)
+    pos[(odd >= 0.002) & (odd < 0.004)] = np.float32(np.inf)
+    pos[(odd >= 0.004) & (odd < 0.006)] = np.float32(-3e19)
+    pos[(odd >= 0.006) & (odd < 0.3)] = 0.0                                       # sky
+    return color, nrm, pos
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("size", [(200, 120), (333, 61), (64, 8), (70, 13)])
+def test_verified_pass_is_the_literal_pass(vrt, oracle, engine, mode, size):
+    import torch
+    W, H = size
+    rng = np.random.default_rng(W * 1000 + H + mode)
+    color, nrm, pos = _hostile_gbuffer(rng, W, H)
+    dev = engine.torch_device
+    c, n, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (color, nrm, pos))
+    for iterations, step, phis in ((2, 2.0, None), (3, 2.0, None), (3, 1.0, None), (2, 2.0, (0.5, 0.2, 30.0)), (2, 4.0, (3.0, 1.0, 1.0))):
+        st = vrt.VoxelRenderSettings(targetResolution=(W, H))
+        d = st.denoiserSettings
+        d.iterations, d.stepWidth, d.mode = iterations, step, mode
+        if phis: d.phiColor0, d.phiNormal0, d.phiPos0 = phis
+        stage = vrt.DenoiserStage(engine, st)
+        assert stage.guard(1) < 0.02, stage.guard(1)
+        engine.set_option("denoise_count", 1)
+        try:
+            got = stage.record(c, n, p).cpu().numpy().copy()
+            redone = [stage.redone(i) for i in range(iterations)]
+            engine.set_option("denoise_verified", 0)
+            lit = vrt.DenoiserStage(engine, st).record(c, n, p).cpu().numpy().copy()
+            assert stage.redone(1) == 0
+        finally:
+            engine.set_option("denoise_verified", 1); engine.set_option("denoise_count", 0)
+        kw = dict(zip(("phi_color0", "phi_normal0", "phi_pos0"), phis)) if phis else {}
+        exp = oracle.denoise(color, nrm, pos, iterations=iterations, step_width0=step, mode=mode, **kw)
+        assert (lit == exp).all()
+        assert (got == exp).all(), (iterations, step, int((got != exp).sum()))
+        assert redone[0] == 0 and redone[1] < W * H // 4 and (redone[1] > 0 or W * H < 10000), redone   # pass 0 has no weights; a few per cent are redone
+
+
+def test_verified_pass_leaves_room(vrt, engine):
+    """1080p of hostile input: with an EIGHTH of the guard the pair still reproduces the exact kernels -- the bound is not
+    within a factor of eight of what the arithmetic does (evidence, not proof: the proof is the header's)."""
+    import torch
+    W, H = 1920, 1080
+    rng = np.random.default_rng(5)
+    color, nrm, pos = _hostile_gbuffer(rng, W, H)
+    dev = engine.torch_device
+    c, n, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (color, nrm, pos))
+    st = vrt.VoxelRenderSettings(targetResolution=(W, H))
+    st.denoiserSettings.iterations = 3
+    engine.set_option("denoise_verified", 0)
+    try:
+        lit = vrt.DenoiserStage(engine, st).record(c, n, p).cpu().numpy().copy()
+    finally:
+        engine.set_option("denoise_verified", 1)
+    stage = vrt.DenoiserStage(engine, st)
+    engine.set_option("denoise_count", 1)
+    try:
+        got = stage.record(c, n, p).cpu().numpy().copy()
+        full = [stage.redone(i) for i in (1, 2)]
+        assert (got == lit).all(), int((got != lit).sum())
+        engine.set_option("denoise_guard_div8", 1)
+        got8 = stage.record(c, n, p).cpu().numpy().copy()
+        eighth = [stage.redone(i) for i in (1, 2)]
+    finally:
+        engine.set_option("denoise_guard_div8", 0); engine.set_option("denoise_count", 0)
+    print("guards", stage.guard(1), stage.guard(2), "redone", full, "with guard / 8", eighth, "of", W * H, "differing", int((got8 != lit).sum()))
+    assert (got8 == lit).all(), int((got8 != lit).sum())
+    assert all(0 < e < f for e, f in zip(eighth, full))

@@ -108,6 +108,8 @@ SYMBOLS = {
     "vrt_denoise": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(DenoiserSettings), _P, _P, _P, _P, _P,
                               C.POINTER(Shard), C.POINTER(_P)]),
     "vrt_denoise_halo_rows": (C.c_int, [C.POINTER(DenoiserSettings)]),
+    "vrt_denoise_guard": (C.c_int, [C.POINTER(DenoiserSettings), C.c_int32, C.POINTER(C.c_float)]),
+    "vrt_debug_denoise_redone": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint32)]),
     "vrt_shard_rows": (C.c_int, [C.c_int32, C.POINTER(Shard)]),
     "vrt_pack_rows": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),
     "vrt_unpack_rows": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Shard)]),

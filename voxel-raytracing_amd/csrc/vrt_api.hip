@@ -17,6 +17,7 @@
 #include "image_io.h"
 #include "vox_reader.h"
 #include "vrt_internal.h"
+#include "vrt_denoise_bound.h"
 
 using namespace vrt;
 
@@ -52,6 +53,9 @@ struct DevOptions {
     int hit_table = 1;         // launches without secondary rays take a hit's colour from the table of colorHit() over materials x normals
     int denoise_th16 = 0;      // the tolerance denoiser on 64 x 16 tiles
     int denoise_packed = 1;    // the exact weighted pass two taps at a time in packed fp32
+    int denoise_verified = 1;  // weighted passes through k_denoise_ver (vrt_denoise_bound.h); 0: the exact kernels compute every pixel
+    int denoise_guard_div8 = 0;// (tests) an eighth of the guard: how much room the bound leaves
+    int denoise_count = 0;     // (tests) count the pixels a verified pass evaluates twice (vrt_debug_denoise_redone)
     int open_cells = 1;        // (scene build) open cells / open bricks in the clearance fields
     int df_prefetch = 1;       // (scene build) secondary rays' look-ups prefetch the neighbouring rows
     int df_own = 1;            // (scene build) AO rays spend their own clearance
@@ -63,6 +67,8 @@ static const OptName kOptNames[] = {
     {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
     {"hit_table", "VRT_HIT_TABLE", &DevOptions::hit_table},
     {"thresh_runs", "VRT_THRESH_RUNS", &DevOptions::thresh_runs}, {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
+    {"denoise_verified", "VRT_DENOISE_VERIFIED", &DevOptions::denoise_verified}, {"denoise_guard_div8", "VRT_DENOISE_GUARD_DIV8", &DevOptions::denoise_guard_div8},
+    {"denoise_count", "VRT_DENOISE_COUNT", &DevOptions::denoise_count},
     {"open_cells", "VRT_OPEN_CELLS", &DevOptions::open_cells}, {"df_prefetch", "VRT_DF_PREFETCH", &DevOptions::df_prefetch},
     {"df_own", "VRT_DF_OWN", &DevOptions::df_own},
 };
@@ -97,6 +103,9 @@ struct vrt_ctx {
     // colorHit() over materials x normals for launches without secondary rays (k_hit_colors), and what it was made from
     uint32_t* hit_colors = nullptr;
     uint64_t hit_scene_gen = 0;
+    // the verified denoiser pass, diagnostics ("denoise_count"): pixels evaluated twice, one set of counters per pass
+    uint32_t* den_counts = nullptr;    // [10 passes][VRT_DENOISE_SEGS]
+    int den_last_passes = 0;           // passes of the latest vrt_denoise call that went through k_denoise_ver (bit i = pass i)
     vrt_settings hit_settings{};
 };
 
@@ -168,6 +177,7 @@ void vrt_ctx_destroy(vrt_ctx* c)
     if (c->hit_list) hipFree(c->hit_list);
     if (c->tile_tags) hipFree(c->tile_tags);
     if (c->hit_colors) hipFree(c->hit_colors);
+    if (c->den_counts) hipFree(c->den_counts);
     if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
     for (int i = 0; i < vrt_ctx::kTabRing; i++) {
         if (c->tab_dev[i]) hipFree(c->tab_dev[i]);
@@ -1185,6 +1195,23 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
     p.tile16 = c->opt.denoise_th16; p.no_packed = c->opt.denoise_packed ? 0 : 1;
     uint8_t* targets[2] = {target0, target1};
     const uint8_t* last = color_in;
+    // which passes take the verified form (whole frame on one rank, a weighted pass, an integral tap offset, a guard worth having)
+    double guards[10];
+    bool any_verified = false;
+    c->den_last_passes = 0;
+    for (int i = 0; i < ds->iterations; i++) {
+        guards[i] = INFINITY;
+        if (i == 0 || !c->opt.denoise_verified || p.sh.nranks != 1 || (size_t)W * (size_t)H >= (1u << 28)) continue;
+        const float inv = 1.0f / (float)i;                     // the pass' parameters as the loop below makes them
+        guards[i] = denoise_guard((double)(inv * ds->phi_color0), (double)(inv * ds->phi_normal0), (double)(inv * ds->phi_pos0),
+                                  (double)((float)i * ds->step_width + 1.0f), (ds->mode & 1) == VRT_DENOISE_AS_SHIPPED);
+        if (guards[i] <= kDenGuardMax) any_verified = true;
+    }
+    const bool counting = any_verified && !(ds->mode & VRT_DENOISE_FAST) && c->opt.denoise_count;
+    if (counting) {
+        if (!c->den_counts) HIPCHK(hipMalloc((void**)&c->den_counts, 10 * VRT_DENOISE_SEGS * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(c->den_counts, 0, (size_t)ds->iterations * VRT_DENOISE_SEGS * sizeof(uint32_t), c->stream));
+    }
     if (c->timing) HIPCHK(hipEventRecord(c->ev_den0, c->stream));
     for (int i = 0; i < ds->iterations; i++) {                 // denoiser_stage.cpp:204-255
         int ping = i % 2;
@@ -1203,6 +1230,19 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
                 p.rc = 1.0f / p.phi_color; p.rn = 1.0f / p.phi_normal; p.rp = 1.0f / p.phi_pos; p.rs = 1.0f / sw2;
             }
         }
+        p.verified = 0;
+        if (guards[i] <= kDenGuardMax) {
+            const double log2e = 1.4426950408889634;
+            const double sw = (double)p.step_width;
+            p.vkc = (float)(log2e / ((double)p.phi_color * 255.0 * 255.0));
+            p.vkn = (float)(log2e / ((double)p.phi_normal * sw * sw * 127.0 * 127.0));
+            p.vkp = (float)(log2e / (double)p.phi_pos);
+            const double g = c->opt.denoise_guard_div8 ? guards[i] * 0.125 : guards[i];
+            p.guard = std::nextafterf((float)g, 1.0f);
+            p.fix_counts = counting ? c->den_counts + (size_t)i * VRT_DENOISE_SEGS : nullptr;
+            p.verified = 1;
+            if (counting) c->den_last_passes |= 1 << i;
+        }
         p.color_in = last; p.color_out = targets[ping];
         int ext = 0;
         if (p.sh.nranks > 1) for (int j = i + 1; j < ds->iterations; j++) ext += tap_reach(ds, j);
@@ -1212,6 +1252,32 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
     }
     if (c->timing) { HIPCHK(hipEventRecord(c->ev_den1, c->stream)); c->have_den = true; }
     *result = last;
+    return VRT_OK;
+}
+
+int vrt_denoise_guard(const vrt_denoiser_settings* ds, int32_t pass, float* guard)
+{
+    if (!ds || !guard) return fail(VRT_ERR_INVALID, "vrt_denoise_guard: NULL argument");
+    if (pass < 1 || pass > 9) return fail(VRT_ERR_INVALID, "vrt_denoise_guard: pass must be 1..9 (pass 0 has no edge-stopping weights)");
+    const float inv = 1.0f / (float)pass;
+    *guard = (float)denoise_guard((double)(inv * ds->phi_color0), (double)(inv * ds->phi_normal0), (double)(inv * ds->phi_pos0),
+                                  (double)((float)pass * ds->step_width + 1.0f), (ds->mode & 1) == VRT_DENOISE_AS_SHIPPED);
+    return VRT_OK;
+}
+
+int vrt_debug_denoise_redone(vrt_ctx* c, int32_t pass, uint32_t* pixels)
+{
+    if (!c || !pixels) return fail(VRT_ERR_INVALID, "vrt_debug_denoise_redone: NULL argument");
+    if (pass < 0 || pass > 9) return fail(VRT_ERR_INVALID, "vrt_debug_denoise_redone: pass must be 0..9");
+    *pixels = 0;
+    if (!(c->den_last_passes & (1 << pass)) || !c->den_counts) return VRT_OK;      // the pass did not take the verified form
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t counts[VRT_DENOISE_SEGS];
+    HIPCHK(hipMemcpy(counts, c->den_counts + (size_t)pass * VRT_DENOISE_SEGS, sizeof counts, hipMemcpyDeviceToHost));
+    uint64_t n = 0;
+    for (uint32_t v : counts) n += v;
+    *pixels = (uint32_t)n;
     return VRT_OK;
 }
 

@@ -1476,14 +1476,10 @@ __device__ __forceinline__ int strip_row(const ShardMap& sh, int extend, int r, 
     return y;
 }
 
+// One pixel of a pass, the shader's own way (denoiser.frag:38-73 tap by tap): the body of k_denoise.
 template <bool PHI_INF>
-__global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
+__device__ __forceinline__ uchar4 denoise_pixel(const DenoiseParams& P, int px, int py)
 {
-    int px = blockIdx.x * 64 + (threadIdx.x & 63);
-    int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    int py = strip_row(P.sh, P.extend, r, P.H);
-    if (py < 0 || px >= P.W) return;
-
     const bool shipped = (P.mode & 1) == VRT_DENOISE_AS_SHIPPED;
     const int ntaps = shipped ? 3 : 9;
     float sw = P.step_width;
@@ -1520,7 +1516,43 @@ __global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
     uchar4 out;
     out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
     out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
-    reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = out;
+    return out;
+}
+
+// One TAP of a weighted pass with an integral tap offset R, the shader's own way: the tap's weight (cw * nw) * pw and its
+// colour texel (k_denoise_ver's redone pixels: sixteen lanes share a pixel, one tap each, so that a pixel costs one tap's
+// chain of dependent instructions instead of nine; the sums are then taken by one lane in the shader's order).  The
+// arithmetic is denoise_pixel<false>'s, operation for operation.
+__device__ __forceinline__ float denoise_tap_weight(const DenoiseParams& P, int px, int py, int tx, int ty, int R, uint32_t& color)
+{
+    const float sw = P.step_width, sw2 = sw * sw;
+    Guides s, o;
+    texel_guides(P, px + tx * R, py + ty * R, o);         // (both texels requested before either is used)
+    texel_guides(P, px, py, s);
+    {
+        int x = px + tx * R, y = py + ty * R;
+        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+        color = reinterpret_cast<const uint32_t*>(P.color_in)[(size_t)y * (size_t)P.W + (size_t)x];
+    }
+    float pw = edge_weight(dist2_4(s.p, o.p), P.phi_pos);
+    float cw = 1.0f, nw = 1.0f;
+    if (pw != 0.0f) {
+        cw = edge_weight(dist2_4(s.c, o.c), P.phi_color);
+        float dn = dist2_4(s.n, o.n);
+        nw = dn == 0.0f ? 1.0f : edge_weight(fmaxf(dn / sw2, 0.0f), P.phi_normal);
+    }
+    return (cw * nw) * pw;
+}
+
+template <bool PHI_INF>
+__global__ __launch_bounds__(256) void k_denoise(const DenoiseParams P)
+{
+    int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int py = strip_row(P.sh, P.extend, r, P.H);
+    if (py < 0 || px >= P.W) return;
+    reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)px] = denoise_pixel<PHI_INF>(P, px, py);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1852,6 +1884,187 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
     }
 }
 
+// ---- the verified pass -----------------------------------------------------------------------------------------------------
+// vrt_denoise_bound.h: of a weighted pass only floor(mean * 255 + 0.5) is ever seen.  This kernel computes the mean cheaply --
+// code distances as exact integers (three v_dot4_u32_u8: |a - b|^2 = a.a + b.b - 2 a.b over the four bytes of a texel; normals
+// biased by 128, which differences do not see), the three edge-stopping weights and the kernel weight as ONE hardware
+// exponential, fused accumulation, a reciprocal -- and every pixel one of whose channels lies within P.guard codes of a
+// rounding boundary (NaN included: the comparison fails) is evaluated once more at the end, the shader's own way
+// (denoise_pixel), by the workgroup that found it.  What the kernel leaves in color_out is the exact kernels' output bit for
+// bit (tests/test_gpu_denoise.py).  FLAG = false is VRT_DENOISE_FAST: the same arithmetic, nothing redone (<= 1 code away).
+//
+// A workgroup owns a column strip of 64 pixels and `seg_rows` rows of it and walks DOWN the strip four rows at a time (one row
+// per wave) through a ring of rows in LDS -- position 16 B, colour and (biased) normal codes 8 B per texel --: while a group
+// of rows is being filtered the four rows the next group adds are already on their way from memory into registers, and go
+// into the ring slots of the four rows the group no longer needs.  A texel is fetched once per strip and segment (1.1 - 1.3x
+// the planes, against 1.9x for 64 x 8 tiles with their halo), the fetch latency hides under the arithmetic, and the launch is
+// ONE round of workgroups that all end together.  RT: the tap offset at compile time (LDS offsets become immediates), 0: any.
+#define VRT_DEN_FIXCAP 1024
+// u - 2 v (a shift and a subtraction).  Not as v_mad_i32_i24 through inline assembly: the result of a v_dot4 may not be read by
+// another vector instruction for three wait states on gfx950, and only instructions the compiler knows get their s_nops -- an
+// asm block here read stale registers; the compiler's own 24-bit multiply-add sign-extends first and is three instructions.
+__device__ __forceinline__ int mad24_minus2(uint32_t v, uint32_t u) { return (int)(u - 2u * v); }
+template <bool SHIPPED, bool FLAG, int RT>
+__global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int Rrt, int seg_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
+    __shared__ uint32_t fl_n;
+    __shared__ uint32_t fl_px[FLAG ? VRT_DEN_FIXCAP : 1];
+    __shared__ float fx_w[FLAG ? 16 : 1][9];
+    __shared__ uint32_t fx_c[FLAG ? 16 : 1][9];
+    const int R = RT ? RT : Rrt;
+    const int RW = 64 + 2 * R;
+    const int U = (4 + 2 * R + 3) / 4;                    // units of four rows a group of four output rows reads
+    const int NR = 4 * (U + 1);                           // ring: those + the unit on its way in
+    float4* lp = lds_g; uint2* lq = reinterpret_cast<uint2*>(lds_g + NR * RW);
+    const int x0 = blockIdx.x * 64, ys = blockIdx.y * seg_rows;
+    const int ye = ys + seg_rows < P.H ? ys + seg_rows : P.H;
+    const int groups = (ye - ys + 3) >> 2;
+    if (FLAG && threadIdx.x == 0) fl_n = 0u;
+    // a thread's two texels of a unit (4 * RW <= 512 of them): row in the unit, clamped frame column
+    const int tA = (int)threadIdx.x, tB = tA + 256;
+    const int rA = tA / RW, cA = tA - rA * RW, rB = tB / RW, cB = tB - rB * RW;
+    const bool hasB = tB < 4 * RW;
+    int xA = x0 - R + cA, xB = x0 - R + cB;
+    xA = xA < 0 ? 0 : (xA > P.W - 1 ? P.W - 1 : xA);
+    xB = xB < 0 ? 0 : (xB > P.W - 1 ? P.W - 1 : xB);
+    const uint32_t* const gc = reinterpret_cast<const uint32_t*>(P.color_in);
+    const uint32_t* const gn = reinterpret_cast<const uint32_t*>(P.normal);
+    const float4* const gp = reinterpret_cast<const float4*>(P.position);
+    float4 pA, pB = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t colA, nrmA, colB = 0u, nrmB = 0u;
+    auto fetch = [&](int unit) {                           // unit u = relative rows 4u .. 4u + 3 = frame rows ys - R + 4u ...
+        int yA = ys - R + 4 * unit + rA, yB = ys - R + 4 * unit + rB;
+        yA = yA < 0 ? 0 : (yA > P.H - 1 ? P.H - 1 : yA);
+        yB = yB < 0 ? 0 : (yB > P.H - 1 ? P.H - 1 : yB);
+        const uint32_t iA = (uint32_t)yA * (uint32_t)P.W + (uint32_t)xA, iB = (uint32_t)yB * (uint32_t)P.W + (uint32_t)xB;
+        pA = gp[iA]; colA = gc[iA]; nrmA = gn[iA];
+        if (hasB) { pB = gp[iB]; colB = gc[iB]; nrmB = gn[iB]; }
+    };
+    auto bias = [](uint32_t n) {
+        // SNORM code -128 decodes like -127 (max(c / 127, -1)): bytes 0x80 become 0x81; then every byte biased by 128
+        uint32_t z = n ^ 0x80808080u;                                                   // bytes that were 0x80 are 0 now
+        z = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);                     // 0x80 exactly in those bytes
+        return (n | (z >> 7)) ^ 0x80808080u;
+    };
+    auto stash = [&](int unit) {
+        const int slot = (unit % (U + 1)) * 4;
+        lp[(slot + rA) * RW + cA] = pA; lq[(slot + rA) * RW + cA] = make_uint2(colA, bias(nrmA));
+        if (hasB) { lp[(slot + rB) * RW + cB] = pB; lq[(slot + rB) * RW + cB] = make_uint2(colB, bias(nrmB)); }
+    };
+    for (int u = 0; u < U; u++) { fetch(u); stash(u); }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lx = threadIdx.x & 63, px = x0 + lx;
+    constexpr int ntaps = SHIPPED ? 3 : 9;
+    const float kc = P.vkc, kn = P.vkn, kp = P.vkp;
+    const float half_guard = 0.5f - P.guard;
+    for (int g = 0; g < groups; g++) {
+        const bool more = g + 1 < groups;
+        if (more) fetch(g + U);                                  // the unit group g + 1 adds: in flight while group g is filtered
+        const int yr = 4 * g + wave, py = ys + yr;               // relative row of the output; its taps' rows are yr, yr + R, yr + 2R in ring terms
+        if (py < ye && px < P.W) {
+            const int b0 = (yr % NR) * RW + lx, b1 = ((yr + R) % NR) * RW + lx, b2 = ((yr + 2 * R) % NR) * RW + lx;   // column of tap tx = -1
+            const uint2 sq = lq[b1 + R];
+            const float4 sp = lp[b1 + R];
+            const uint32_t scc = __builtin_amdgcn_udot4(sq.x, sq.x, 0u, false), snn = __builtin_amdgcn_udot4(sq.y, sq.y, 0u, false);
+            constexpr float kcen = SHIPPED ? kGauss2 : kGauss0;
+            float a0 = (float)(sq.x & 0xFFu) * kcen, a1 = (float)((sq.x >> 8) & 0xFFu) * kcen, a2 = (float)((sq.x >> 16) & 0xFFu) * kcen, a3 = (float)(sq.x >> 24) * kcen;
+            float total = kcen;
+#pragma unroll
+            for (int i = 0; i < ntaps; i++) {
+                int tx, ty;
+                if (SHIPPED) { tx = i == 0 ? -1 : (i == 1 ? 1 : 0); ty = i == 2 ? 0 : -1; }
+                else { tx = i % 3 - 1; ty = i / 3 - 1; }
+                if (tx == 0 && ty == 0) continue;                // the centre tap: every distance is 0, its weight is the kernel's (above)
+                const int ci = (ty < 0 ? b0 : (ty == 0 ? b1 : b2)) + (tx + 1) * R;
+                const uint2 oq = lq[ci];
+                const float4 op = lp[ci];
+                // (u - 2 v as one 24-bit multiply-add: both are below 2^19)
+                const int dc = mad24_minus2(__builtin_amdgcn_udot4(sq.x, oq.x, 0u, false), __builtin_amdgcn_udot4(oq.x, oq.x, scc, false));
+                const int dn = mad24_minus2(__builtin_amdgcn_udot4(sq.y, oq.y, 0u, false), __builtin_amdgcn_udot4(oq.y, oq.y, snn, false));
+                const float dx = sp.x - op.x, dy = sp.y - op.y, dz = sp.z - op.z, dw = sp.w - op.w;
+                const float dp = __builtin_fmaf(dw, dw, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+                // the kernel weight rides in the exponent: w * kern = exp2(-(e + -log2 kern))
+                const float lk = SHIPPED ? shipped_lk(i) : (r2_of(tx, ty) == 1 ? 0.18033688011112042f : 0.36067376022224085f);
+                const float e = __builtin_fmaf(dp, kp, __builtin_fmaf((float)dc, kc, __builtin_fmaf((float)dn, kn, lk)));
+                const float wk = __builtin_amdgcn_exp2f(-e);
+                a0 = __builtin_fmaf((float)(oq.x & 0xFFu), wk, a0);
+                a1 = __builtin_fmaf((float)((oq.x >> 8) & 0xFFu), wk, a1);
+                a2 = __builtin_fmaf((float)((oq.x >> 16) & 0xFFu), wk, a2);
+                a3 = __builtin_fmaf((float)(oq.x >> 24), wk, a3);
+                total += wk;
+            }
+            const float r = __builtin_amdgcn_rcpf(total);
+            // a weighted mean of codes, + 0.5: its floor is the output, its fraction says how far the nearest rounding boundary is
+            const float y0f = __builtin_fmaf(a0, r, 0.5f), y1f = __builtin_fmaf(a1, r, 0.5f), y2f = __builtin_fmaf(a2, r, 0.5f), y3f = __builtin_fmaf(a3, r, 0.5f);
+            const float f0 = __builtin_amdgcn_fractf(y0f), f1 = __builtin_amdgcn_fractf(y1f), f2 = __builtin_amdgcn_fractf(y2f), f3 = __builtin_amdgcn_fractf(y3f);
+            const uint32_t o0 = (uint32_t)fminf(y0f - f0, 255.0f), o1 = (uint32_t)fminf(y1f - f1, 255.0f), o2 = (uint32_t)fminf(y2f - f2, 255.0f), o3 = (uint32_t)fminf(y3f - f3, 255.0f);
+            const uint32_t idx = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
+            // sure <=> every channel's fraction lies further than the guard from 0 and from 1 (a NaN mean compares false)
+            const bool sure = !FLAG || (__builtin_fabsf(f0 - 0.5f) < half_guard && __builtin_fabsf(f1 - 0.5f) < half_guard &&
+                                        __builtin_fabsf(f2 - 0.5f) < half_guard && __builtin_fabsf(f3 - 0.5f) < half_guard);
+            if (sure) reinterpret_cast<uint32_t*>(P.color_out)[idx] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+            else if (FLAG) { const uint32_t slot = atomicAdd(&fl_n, 1u); if (slot < VRT_DEN_FIXCAP) fl_px[slot] = idx; }
+        }
+        if (more) stash(g + U);                                  // into the slots of the unit group g no longer reads
+        __syncthreads();
+    }
+    if (FLAG) {
+        // (the loop's last barrier is behind us: fl_n and fl_px are final)
+        const uint32_t n = fl_n;
+        if (n == 0u) return;                                     // uniform per workgroup
+        if (P.fix_counts && threadIdx.x == 0) atomicAdd(&P.fix_counts[(blockIdx.y * gridDim.x + blockIdx.x) & (VRT_DENOISE_SEGS - 1u)], n);
+        if (n <= VRT_DEN_FIXCAP) {
+            // sixteen lanes per listed pixel, a tap each (denoise_tap_weight); lane 0 of the sixteen sums in the shader's order
+            const bool shipped = SHIPPED;
+            const int tap = (int)(threadIdx.x & 15u);
+            int tx, ty;
+            if (shipped) { tx = tap == 0 ? -1 : (tap == 1 ? 1 : 0); ty = tap == 2 ? 0 : -1; }
+            else { tx = tap % 3 - 1; ty = tap / 3 - 1; }
+            for (uint32_t base = 0; base < n; base += 16u) {
+                const uint32_t e = base + (threadIdx.x >> 4);
+                const bool live = e < n;
+                const uint32_t idx = live ? fl_px[e] : 0u;
+                const int py = (int)(idx / (uint32_t)P.W), qx = (int)(idx - (uint32_t)py * (uint32_t)P.W);
+                if (live && tap < ntaps) {
+                    uint32_t col;
+                    const float w = denoise_tap_weight(P, qx, py, tx, ty, R, col);
+                    fx_w[threadIdx.x >> 4][tap] = w; fx_c[threadIdx.x >> 4][tap] = col;
+                }
+                __syncthreads();
+                if (live && tap == 0) {
+                    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, total = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < ntaps; i++) {
+                        float kern;
+                        if (shipped) kern = i == 1 ? kGauss0 : kGauss2;
+                        else { const int ux = i % 3 - 1, uy = i / 3 - 1, r2 = ux * ux + uy * uy; kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2); }
+                        const float w = fx_w[threadIdx.x >> 4][i];
+                        const uint32_t cc = fx_c[threadIdx.x >> 4][i];
+                        const float oc[4] = {decode_unorm8(cc & 0xFFu), decode_unorm8((cc >> 8) & 0xFFu), decode_unorm8((cc >> 16) & 0xFFu), decode_unorm8(cc >> 24)};
+                        for (int k = 0; k < 4; k++) sum[k] += (oc[k] * w) * kern;
+                        total += w * kern;
+                    }
+                    uchar4 out;
+                    out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
+                    out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
+                    reinterpret_cast<uchar4*>(P.color_out)[idx] = out;
+                }
+                __syncthreads();
+            }
+        } else {
+            // more than the list holds (hostile input): every pixel of the segment the shader's own way -- pixels that were
+            // sure get the value they already have
+            for (int t = (int)threadIdx.x; t < 64 * (ye - ys); t += 256) {
+                const int py = ys + (t >> 6), qx = x0 + (t & 63);
+                if (qx < P.W) reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)qx] = denoise_pixel<false>(P, qx, py);
+            }
+        }
+    }
+}
+
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
 {
     int per = p.sh.strip_rows + 2 * p.extend;
@@ -1867,7 +2080,28 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     if (tiled) {
         size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * (inf ? 16 : 48);   // pass 0 stages the colour plane only
         const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
-        if (!inf && (p.mode & VRT_DENOISE_FAST) && p.sh.nranks == 1 && p.extend == 0) {
+        if (!inf && p.verified && p.sh.nranks == 1 && p.extend == 0) {
+            // the verified pass (exact output) or, with VRT_DENOISE_FAST, its cheap half alone: ONE round of workgroups, each a
+            // 64-pixel column strip x seg_rows rows (four workgroups per compute unit fit)
+            const int strips = (p.W + 63) / 64;
+            int per = 1024 / strips; if (per < 1) per = 1;            // (the literal evaluation at the end costs 115 VGPRs: four workgroups per compute unit)
+            int seg_rows = ((p.H + per - 1) / per + 3) & ~3; if (seg_rows < 8) seg_rows = 8;
+            dim3 g2((unsigned)strips, (unsigned)((p.H + seg_rows - 1) / seg_rows));
+            const int U = (4 + 2 * R + 3) / 4;
+            const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(4 * (U + 1)) * 24;
+            const bool flag = !(p.mode & VRT_DENOISE_FAST);
+#define VRT_LAUNCH_VER(SH_, FL_)                                                                                                  \
+            switch (R) {                                                                                                          \
+            case 2:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 2>), g2, block, l2, s, p, R, seg_rows); break;                       \
+            case 3:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 3>), g2, block, l2, s, p, R, seg_rows); break;                       \
+            case 5:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 5>), g2, block, l2, s, p, R, seg_rows); break;                       \
+            default: hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 0>), g2, block, l2, s, p, R, seg_rows); break;                       \
+            }
+            if (flag) { if (shipped) { VRT_LAUNCH_VER(true, true) } else { VRT_LAUNCH_VER(false, true) } }
+            else      { if (shipped) { VRT_LAUNCH_VER(true, false) } else { VRT_LAUNCH_VER(false, false) } }
+#undef VRT_LAUNCH_VER
+        }
+        else if (!inf && (p.mode & VRT_DENOISE_FAST) && p.sh.nranks == 1 && p.extend == 0) {
             const int th = p.tile16 ? 16 : 8;                                // development switch: tile height 8 / 16
             dim3 g2((unsigned)((p.W + 63) / 64), (unsigned)((p.H + th - 1) / th));
             const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(th + 2 * R) * 48;

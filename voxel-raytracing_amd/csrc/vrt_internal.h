@@ -203,6 +203,7 @@ struct GeomParams {
     const uint32_t* hit_colors;
 };
 
+#define VRT_DENOISE_SEGS 64    // counters of redone pixels (diagnostics): a workgroup adds to counter (its index % 64)
 struct DenoiseParams {
     const uint8_t* color_in;
     const int8_t*  normal;
@@ -217,6 +218,12 @@ struct DenoiseParams {
     int32_t extend;            // rows beyond each owned strip that this pass must also produce
     int32_t tile16;            // development switch (context option "denoise_th16"): the tolerance kernel on 64 x 16 tiles instead of 64 x 8
     int32_t no_packed;         // development switch (context option "denoise_packed" = 0): the exact weighted pass tap by tap
+    // the verified pass (k_denoise_ver, vrt_denoise_bound.h): scale factors on the integer code distances and on the position
+    // distance (log2(e) / phi, the colour's also / 255^2, the normal's / (127^2 stepWidth^2); computed in double), the guard in
+    // RGBA8 codes, and -- diagnostics, else NULL -- VRT_DENOISE_SEGS counters of the pixels the pass evaluated twice
+    float   vkc, vkn, vkp, guard;
+    uint32_t* fix_counts;
+    int32_t verified;          // 1: this pass may take k_denoise_ver (host: eligible and the guard is small)
     ShardMap sh;
 };
 

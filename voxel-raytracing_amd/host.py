@@ -671,6 +671,19 @@ class DenoiserStage:
                 return t
         return colorInput
 
+    def guard(self, pass_index: int) -> float:
+        """Guard (RGBA8 codes) of weighted pass `pass_index` under the current settings (vrt_denoise_guard); inf: computed literally."""
+        ds = self._settings.denoiser_to_c()
+        g = C.c_float()
+        check(lib().vrt_denoise_guard(C.byref(ds), int(pass_index), C.byref(g)))
+        return float(g.value)
+
+    def redone(self, pass_index: int) -> int:
+        """Pixels of pass `pass_index` that the latest record() on this engine evaluated a second time, literally."""
+        n = C.c_uint32()
+        check(lib().vrt_debug_denoise_redone(self.engine.ctx, int(pass_index), C.byref(n)))
+        return int(n.value)
+
 
 class UpscalerStage:
     """UpscalerStage (upscaler_stage.cpp).  update() reproduces the jitter / frame sequence of :59-70 bit for bit
