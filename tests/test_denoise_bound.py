@@ -1,0 +1,106 @@
+"""The constants the verified denoiser pass rests on (csrc/vrt_denoise_bound.h), re-measured on the CPU:
+  * the decode roundings of the spec's squared code differences, over ALL pairs of codes (C1 colour / normal);
+  * the relative error of min(exp_spec(x), 1) (the oracle's vo_expf = csrc/vrt_spec.h exp_spec) against libm in double, on a
+    sample here and exhaustively by tools/exp_spec_error.c (1.12e9 inputs: 1.364 eps);
+  * the guard the library reports (vrt_denoise_guard, no device needed) against the header's formula evaluated here with
+    the MEASURED constants: the library's must not be smaller;
+  * the guard's eligibility rules.
+A change of the numeric spec (decode, exp) that widens an error shows up here before it can become a wrong pixel."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+EPS = 2.0 ** -24
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "voxel-raytracing_amd", "csrc", "vrt_denoise_bound.h")
+
+
+def _header_constant(name):
+    m = re.search(r"constexpr double %s = ([0-9.]+) \* kDenEps;" % name, open(HEADER).read())
+    assert m, name
+    return float(m.group(1)) * EPS
+
+
+def _decode_c1(D, lo, hi):
+    c = np.arange(lo, hi + 1, dtype=np.float32)
+    dec = (c / np.float32(D)).astype(np.float32)                        # IEEE quotient: the spec's decode
+    t = (dec[:, None] - dec[None, :]).astype(np.float32)
+    t2 = (t * t).astype(np.float32)
+    ex = (c[:, None].astype(np.float64) - c[None, :].astype(np.float64)) / D
+    d = np.abs(t2.astype(np.float64) - ex * ex)
+    same = ex == 0
+    assert (t2[same] == 0).all()                                         # equal codes: distance exactly 0
+    return float((d[~same] / np.abs(ex[~same])).max())
+
+
+def test_decode_constants_cover_every_pair_of_codes():
+    c1c, c1n = _decode_c1(255, 0, 255), _decode_c1(127, -127, 127)
+    print("C1 colour %.3f eps, normal %.3f eps" % (c1c / EPS, c1n / EPS))
+    assert c1c <= _header_constant("kDenC1Color") and c1n <= _header_constant("kDenC1Normal")
+    assert c1c > 1.5 * EPS and c1n > 3.0 * EPS                            # (the header's are not wildly loose either)
+
+
+def test_exp_spec_error_sample(oracle):
+    lib = oracle.lib()
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([-rng.uniform(0, 87, 300000), -np.exp(rng.uniform(-40, 4.46, 100000)),
+                         np.float32(-59.9505272) + np.arange(-2000, 2000) * np.float32(3.8e-6)]).astype(np.float32)
+    xs = xs[(xs >= -87) & (xs <= 0)]
+    worst = 0.0
+    for x in xs:
+        r = min(float(lib.vo_expf(C.c_float(float(x)))), 1.0)
+        t = math.exp(float(x))
+        worst = max(worst, abs(r - t) / t)
+    print("worst relative error of min(exp_spec, 1) on the sample: %.3f eps" % (worst / EPS))
+    assert worst <= _header_constant("kDenExpSpec")
+    assert float(lib.vo_expf(C.c_float(-0.0))) == 1.0 and float(lib.vo_expf(C.c_float(-87.5))) == 0.0
+
+
+def _guard_here(phi_c, phi_n, phi_p, sw, shipped, c1c, c1n, ex):
+    G0, G1, G2 = 1.0, 0.8824969025845955, 0.7788007830714049
+    kcen = G2 if shipped else G0
+    K = G2 + G0 if shipped else 4 * G1 + 4 * G2
+    n = 2 if shipped else 8
+    An = sw * sw * phi_n
+    alpha = 0.8578 * (c1c / math.sqrt(phi_c) + c1n / math.sqrt(An)) + 0.3679 * (4.02 + 5.03 + 7.05) * EPS
+    spec = (3 * ex + 2 * EPS) + alpha * K / kcen + 21.3 * EPS
+    fast = 2 * EPS + n * 2.962 * EPS / kcen + 19 * EPS
+    return 255.0 * (spec + fast) + 767 * EPS
+
+
+def test_library_guard_is_not_below_the_formula_with_measured_constants(vrt):
+    c1c, c1n, ex = _decode_c1(255, 0, 255), _decode_c1(127, -127, 127), 1.364 * EPS
+    lib = vrt.lib()
+    for phis in ((20.4, 0.01, 0.1), (0.5, 0.2, 30.0), (3.0, 1.0, 1.0), (1e-3, 1e-3, 1e-3), (1e4, 1e4, 1e4)):
+        for step in (1.0, 2.0, 4.0):
+            for mode in (0, 1):
+                for pss in (1, 2):
+                    sw = pss * step + 1.0
+                    if sw > 5:
+                        continue
+                    d = vrt._capi.DenoiserSettings(3, phis[0], phis[1], phis[2], step, mode)
+                    g = C.c_float()
+                    assert lib.vrt_denoise_guard(C.byref(d), pss, C.byref(g)) == 0
+                    f32 = lambda v: float(np.float32(v))
+                    inv = np.float32(1.0) / np.float32(pss)
+                    here = _guard_here(f32(inv * np.float32(phis[0])), f32(inv * np.float32(phis[1])), f32(inv * np.float32(phis[2])), sw, mode == 1, c1c, c1n, ex)
+                    assert g.value >= here, (phis, step, mode, pss, g.value, here)
+    d = vrt._capi.DenoiserSettings(2, 20.4, 0.01, 0.1, 2.0, 0)
+    g = C.c_float()
+    lib.vrt_denoise_guard(C.byref(d), 1, C.byref(g))
+    assert 2.5e-3 < g.value < 3.5e-3                                       # the reference's defaults: 3.1e-3 of a code
+    lib.vrt_denoise_guard(C.byref(d), 0, C.byref(g))
+    assert 3e-4 < g.value < 7e-4                                           # pass 0: a plain blur
+
+
+def test_guard_eligibility(vrt):
+    lib = vrt.lib()
+    g = C.c_float()
+    for phis, step, pss in (((20.4, 0.01, 0.1), 1.5, 1), ((20.4, 0.01, 0.1), 2.0, 3), ((1e-7, 0.01, 0.1), 2.0, 1), ((20.4, 0.01, 3e6), 2.0, 1)):
+        d = vrt._capi.DenoiserSettings(4, phis[0], phis[1], phis[2], step, 0)
+        assert lib.vrt_denoise_guard(C.byref(d), pss, C.byref(g)) == 0
+        assert math.isinf(g.value), (phis, step, pss)                      # fractional / too wide tap offsets, parameters out of range
+    assert lib.vrt_denoise_guard(C.byref(d), 10, C.byref(g)) != 0

@@ -169,7 +169,7 @@ def test_verified_pass_is_the_literal_pass(vrt, oracle, engine, mode, size):
         exp = oracle.denoise(color, nrm, pos, iterations=iterations, step_width0=step, mode=mode, **kw)
         assert (lit == exp).all()
         assert (got == exp).all(), (iterations, step, int((got != exp).sum()))
-        assert redone[0] == 0 and redone[1] < W * H // 4 and (redone[1] > 0 or W * H < 10000), redone   # pass 0 has no weights; a few per cent are redone
+        assert max(redone) < W * H // 4 and (redone[1] > 0 or W * H < 10000), redone                  # a few per cent are redone
 
 
 def test_verified_pass_leaves_room(vrt, engine):

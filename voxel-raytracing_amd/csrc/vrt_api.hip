@@ -1201,7 +1201,8 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
     c->den_last_passes = 0;
     for (int i = 0; i < ds->iterations; i++) {
         guards[i] = INFINITY;
-        if (i == 0 || !c->opt.denoise_verified || p.sh.nranks != 1 || (size_t)W * (size_t)H >= (1u << 28)) continue;
+        if (!c->opt.denoise_verified || p.sh.nranks != 1 || (size_t)W * (size_t)H >= (1u << 28)) continue;
+        if (i == 0) { guards[0] = denoise_guard_pass0(); any_verified = true; continue; }      // pass 0: a plain blur, tap offset 1
         const float inv = 1.0f / (float)i;                     // the pass' parameters as the loop below makes them
         guards[i] = denoise_guard((double)(inv * ds->phi_color0), (double)(inv * ds->phi_normal0), (double)(inv * ds->phi_pos0),
                                   (double)((float)i * ds->step_width + 1.0f), (ds->mode & 1) == VRT_DENOISE_AS_SHIPPED);
@@ -1258,7 +1259,8 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
 int vrt_denoise_guard(const vrt_denoiser_settings* ds, int32_t pass, float* guard)
 {
     if (!ds || !guard) return fail(VRT_ERR_INVALID, "vrt_denoise_guard: NULL argument");
-    if (pass < 1 || pass > 9) return fail(VRT_ERR_INVALID, "vrt_denoise_guard: pass must be 1..9 (pass 0 has no edge-stopping weights)");
+    if (pass < 0 || pass > 9) return fail(VRT_ERR_INVALID, "vrt_denoise_guard: pass must be 0..9");
+    if (pass == 0) { *guard = (float)denoise_guard_pass0(); return VRT_OK; }
     const float inv = 1.0f / (float)pass;
     *guard = (float)denoise_guard((double)(inv * ds->phi_color0), (double)(inv * ds->phi_normal0), (double)(inv * ds->phi_pos0),
                                   (double)((float)pass * ds->step_width + 1.0f), (ds->mode & 1) == VRT_DENOISE_AS_SHIPPED);

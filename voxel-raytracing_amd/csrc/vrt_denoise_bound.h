@@ -2,8 +2,8 @@
 //
 // denoiser.frag:38-73 ends in a RGBA8 target: of everything a weighted pass computes for a pixel only floor(mean * 255 + 0.5)
 // per channel is ever seen.  k_denoise_ver evaluates the mean with the hardware's exponential and reciprocal, fused
-// multiply-adds and exact integer code distances, and k_denoise_fix redoes -- the shader's own way, the numeric spec's
-// operations one by one -- every pixel whose cheap mean lies within `guard` codes of a rounding boundary.  The result is the
+// multiply-adds and exact integer code distances, and then redoes -- the shader's own way, the numeric spec's operations
+// one by one -- every pixel whose cheap mean lies within `guard` codes of a rounding boundary.  The result is the
 // spec's, bit for bit, as long as
 //
 //        | y_fast - y_spec |  <=  guard          (both in RGBA8 code units, before the floor)
@@ -70,6 +70,15 @@ inline double denoise_guard(double phi_color, double phi_normal, double phi_pos,
     const double spec = (3.0 * kDenExpSpec + 2.0 * eps) + alpha_s * K / kcen + 21.3 * eps;
     const double fast = 2.0 * eps + n * (2.962 * eps + 1e-37) / kcen + 19.0 * eps;
     return 1.01 * 255.0 * (spec + fast) + 767.0 * eps;
+}
+
+// Pass 0 (phi = +inf: every edge-stopping weight is exactly 1, the pass is a plain 3 x 3 blur; tap offset 1).  The spec: a term
+// RN(RN(c / 255) kappa) carries 2 eps, eight additions 8 eps, the total's eight additions 8 eps, the quotient 1 eps: 19.2 eps
+// relative on a value <= 1, then 511 eps codes of the two final roundings.  The cheap form: nine fused accumulations of
+// code * kappa, the reciprocal of the weights' sum rounded once from double, one fused multiply-add: 10.1 eps relative, 256 eps.
+inline double denoise_guard_pass0()
+{
+    return 1.01 * 255.0 * (19.2 + 10.1) * kDenEps + 767.0 * kDenEps;
 }
 
 } // namespace vrt

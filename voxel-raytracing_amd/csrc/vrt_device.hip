@@ -1904,7 +1904,7 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
 // another vector instruction for three wait states on gfx950, and only instructions the compiler knows get their s_nops -- an
 // asm block here read stale registers; the compiler's own 24-bit multiply-add sign-extends first and is three instructions.
 __device__ __forceinline__ int mad24_minus2(uint32_t v, uint32_t u) { return (int)(u - 2u * v); }
-template <bool SHIPPED, bool FLAG, int RT>
+template <bool SHIPPED, bool FLAG, int RT, bool PASS0 = false>
 __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int Rrt, int seg_rows)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
@@ -1917,6 +1917,7 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     const int U = (4 + 2 * R + 3) / 4;                    // units of four rows a group of four output rows reads
     const int NR = 4 * (U + 1);                           // ring: those + the unit on its way in
     float4* lp = lds_g; uint2* lq = reinterpret_cast<uint2*>(lds_g + NR * RW);
+    uint32_t* lc = reinterpret_cast<uint32_t*>(lds_g);      // PASS0 (phi = +inf, every weight exactly 1): the ring holds the colour codes only
     const int x0 = blockIdx.x * 64, ys = blockIdx.y * seg_rows;
     const int ye = ys + seg_rows < P.H ? ys + seg_rows : P.H;
     const int groups = (ye - ys + 3) >> 2;
@@ -1931,13 +1932,14 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     const uint32_t* const gc = reinterpret_cast<const uint32_t*>(P.color_in);
     const uint32_t* const gn = reinterpret_cast<const uint32_t*>(P.normal);
     const float4* const gp = reinterpret_cast<const float4*>(P.position);
-    float4 pA, pB = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t colA, nrmA, colB = 0u, nrmB = 0u;
+    float4 pA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pB = pA;
+    uint32_t colA, nrmA = 0u, colB = 0u, nrmB = 0u;
     auto fetch = [&](int unit) {                           // unit u = relative rows 4u .. 4u + 3 = frame rows ys - R + 4u ...
         int yA = ys - R + 4 * unit + rA, yB = ys - R + 4 * unit + rB;
         yA = yA < 0 ? 0 : (yA > P.H - 1 ? P.H - 1 : yA);
         yB = yB < 0 ? 0 : (yB > P.H - 1 ? P.H - 1 : yB);
         const uint32_t iA = (uint32_t)yA * (uint32_t)P.W + (uint32_t)xA, iB = (uint32_t)yB * (uint32_t)P.W + (uint32_t)xB;
+        if (PASS0) { colA = gc[iA]; if (hasB) colB = gc[iB]; return; }
         pA = gp[iA]; colA = gc[iA]; nrmA = gn[iA];
         if (hasB) { pB = gp[iB]; colB = gc[iB]; nrmB = gn[iB]; }
     };
@@ -1949,6 +1951,7 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     };
     auto stash = [&](int unit) {
         const int slot = (unit % (U + 1)) * 4;
+        if (PASS0) { lc[(slot + rA) * RW + cA] = colA; if (hasB) lc[(slot + rB) * RW + cB] = colB; return; }
         lp[(slot + rA) * RW + cA] = pA; lq[(slot + rA) * RW + cA] = make_uint2(colA, bias(nrmA));
         if (hasB) { lp[(slot + rB) * RW + cB] = pB; lq[(slot + rB) * RW + cB] = make_uint2(colB, bias(nrmB)); }
     };
@@ -1966,9 +1969,9 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
         const int yr = 4 * g + wave, py = ys + yr;               // relative row of the output; its taps' rows are yr, yr + R, yr + 2R in ring terms
         if (py < ye && px < P.W) {
             const int b0 = (yr % NR) * RW + lx, b1 = ((yr + R) % NR) * RW + lx, b2 = ((yr + 2 * R) % NR) * RW + lx;   // column of tap tx = -1
-            const uint2 sq = lq[b1 + R];
-            const float4 sp = lp[b1 + R];
-            const uint32_t scc = __builtin_amdgcn_udot4(sq.x, sq.x, 0u, false), snn = __builtin_amdgcn_udot4(sq.y, sq.y, 0u, false);
+            uint2 sq; float4 sp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (PASS0) sq = make_uint2(lc[b1 + R], 0u); else { sq = lq[b1 + R]; sp = lp[b1 + R]; }
+            const uint32_t scc = PASS0 ? 0u : __builtin_amdgcn_udot4(sq.x, sq.x, 0u, false), snn = PASS0 ? 0u : __builtin_amdgcn_udot4(sq.y, sq.y, 0u, false);
             constexpr float kcen = SHIPPED ? kGauss2 : kGauss0;
             float a0 = (float)(sq.x & 0xFFu) * kcen, a1 = (float)((sq.x >> 8) & 0xFFu) * kcen, a2 = (float)((sq.x >> 16) & 0xFFu) * kcen, a3 = (float)(sq.x >> 24) * kcen;
             float total = kcen;
@@ -1979,6 +1982,15 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
                 else { tx = i % 3 - 1; ty = i / 3 - 1; }
                 if (tx == 0 && ty == 0) continue;                // the centre tap: every distance is 0, its weight is the kernel's (above)
                 const int ci = (ty < 0 ? b0 : (ty == 0 ? b1 : b2)) + (tx + 1) * R;
+                if (PASS0) {                                     // every edge-stopping weight is exactly 1: the tap's weight is the kernel's
+                    const uint32_t oc = lc[ci];
+                    const float kk = SHIPPED ? (i == 1 ? kGauss0 : kGauss2) : (r2_of(tx, ty) == 1 ? kGauss1 : kGauss2);
+                    a0 = __builtin_fmaf((float)(oc & 0xFFu), kk, a0);
+                    a1 = __builtin_fmaf((float)((oc >> 8) & 0xFFu), kk, a1);
+                    a2 = __builtin_fmaf((float)((oc >> 16) & 0xFFu), kk, a2);
+                    a3 = __builtin_fmaf((float)(oc >> 24), kk, a3);
+                    continue;
+                }
                 const uint2 oq = lq[ci];
                 const float4 op = lp[ci];
                 // (u - 2 v as one 24-bit multiply-add: both are below 2^19)
@@ -1996,7 +2008,8 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
                 a3 = __builtin_fmaf((float)(oq.x >> 24), wk, a3);
                 total += wk;
             }
-            const float r = __builtin_amdgcn_rcpf(total);
+            // (PASS0: the weights' sum is a constant; its reciprocal rounded once from double)
+            const float r = PASS0 ? (SHIPPED ? (float)(1.0 / (2.0 * 0.7788007830714049 + 1.0)) : (float)(1.0 / (1.0 + 4.0 * 0.8824969025845955 + 4.0 * 0.7788007830714049))) : __builtin_amdgcn_rcpf(total);
             // a weighted mean of codes, + 0.5: its floor is the output, its fraction says how far the nearest rounding boundary is
             const float y0f = __builtin_fmaf(a0, r, 0.5f), y1f = __builtin_fmaf(a1, r, 0.5f), y2f = __builtin_fmaf(a2, r, 0.5f), y3f = __builtin_fmaf(a3, r, 0.5f);
             const float f0 = __builtin_amdgcn_fractf(y0f), f1 = __builtin_amdgcn_fractf(y1f), f2 = __builtin_amdgcn_fractf(y2f), f3 = __builtin_amdgcn_fractf(y3f);
@@ -2016,21 +2029,35 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
         const uint32_t n = fl_n;
         if (n == 0u) return;                                     // uniform per workgroup
         if (P.fix_counts && threadIdx.x == 0) atomicAdd(&P.fix_counts[(blockIdx.y * gridDim.x + blockIdx.x) & (VRT_DENOISE_SEGS - 1u)], n);
-        if (n <= VRT_DEN_FIXCAP) {
-            // sixteen lanes per listed pixel, a tap each (denoise_tap_weight); lane 0 of the sixteen sums in the shader's order
+        {
+            // sixteen lanes per listed pixel, a tap each (denoise_tap_weight); lane 0 of the sixteen sums in the shader's order.
+            // (More flagged than the list holds -- hostile input --: every pixel of the segment instead; pixels that were sure
+            // get the value they already have.)
+            const bool overflow = n > VRT_DEN_FIXCAP;
+            const uint32_t entries = overflow ? 64u * (uint32_t)(ye - ys) : n;
             const bool shipped = SHIPPED;
             const int tap = (int)(threadIdx.x & 15u);
             int tx, ty;
             if (shipped) { tx = tap == 0 ? -1 : (tap == 1 ? 1 : 0); ty = tap == 2 ? 0 : -1; }
             else { tx = tap % 3 - 1; ty = tap / 3 - 1; }
-            for (uint32_t base = 0; base < n; base += 16u) {
+            for (uint32_t base = 0; base < entries; base += 16u) {
                 const uint32_t e = base + (threadIdx.x >> 4);
-                const bool live = e < n;
-                const uint32_t idx = live ? fl_px[e] : 0u;
+                bool live = e < entries;
+                uint32_t idx = 0u;
+                if (live) {
+                    if (overflow) { const uint32_t qx = (uint32_t)x0 + (e & 63u); live = qx < (uint32_t)P.W; idx = (uint32_t)(ys + (int)(e >> 6)) * (uint32_t)P.W + qx; }
+                    else idx = fl_px[e];
+                }
                 const int py = (int)(idx / (uint32_t)P.W), qx = (int)(idx - (uint32_t)py * (uint32_t)P.W);
                 if (live && tap < ntaps) {
                     uint32_t col;
-                    const float w = denoise_tap_weight(P, qx, py, tx, ty, R, col);
+                    float w = 1.0f;
+                    if (PASS0) {
+                        int x = qx + tx * R, y = py + ty * R;
+                        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+                        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+                        col = reinterpret_cast<const uint32_t*>(P.color_in)[(size_t)y * (size_t)P.W + (size_t)x];
+                    } else w = denoise_tap_weight(P, qx, py, tx, ty, R, col);
                     fx_w[threadIdx.x >> 4][tap] = w; fx_c[threadIdx.x >> 4][tap] = col;
                 }
                 __syncthreads();
@@ -2054,13 +2081,6 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
                 }
                 __syncthreads();
             }
-        } else {
-            // more than the list holds (hostile input): every pixel of the segment the shader's own way -- pixels that were
-            // sure get the value they already have
-            for (int t = (int)threadIdx.x; t < 64 * (ye - ys); t += 256) {
-                const int py = ys + (t >> 6), qx = x0 + (t & 63);
-                if (qx < P.W) reinterpret_cast<uchar4*>(P.color_out)[(size_t)py * (size_t)P.W + (size_t)qx] = denoise_pixel<false>(P, qx, py);
-            }
         }
     }
 }
@@ -2080,11 +2100,25 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     if (tiled) {
         size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * (inf ? 16 : 48);   // pass 0 stages the colour plane only
         const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
-        if (!inf && p.verified && p.sh.nranks == 1 && p.extend == 0) {
+        if (inf && p.verified && p.sh.nranks == 1 && p.extend == 0 && !(p.mode & VRT_DENOISE_FAST)) {
+            // pass 0 the same way: the ring holds the colour plane only, the weights are the kernel's
+            // (34 VGPRs and 9 KB of LDS: eight workgroups per compute unit, whose groups of rows hide each other's fetches)
+            const int strips = (p.W + 63) / 64;
+            int per = 2048 / strips; if (per < 1) per = 1;
+            int seg_rows = ((p.H + per - 1) / per + 3) & ~3; if (seg_rows < 8) seg_rows = 8;
+            dim3 g2((unsigned)strips, (unsigned)((p.H + seg_rows - 1) / seg_rows));
+            const int U = (4 + 2 * R + 3) / 4;
+            const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(4 * (U + 1)) * 4;
+            if (R == 1) { if (shipped) hipLaunchKernelGGL((k_denoise_ver<true, true, 1, true>), g2, block, l2, s, p, R, seg_rows);
+                          else         hipLaunchKernelGGL((k_denoise_ver<false, true, 1, true>), g2, block, l2, s, p, R, seg_rows); }
+            else        { if (shipped) hipLaunchKernelGGL((k_denoise_ver<true, true, 0, true>), g2, block, l2, s, p, R, seg_rows);
+                          else         hipLaunchKernelGGL((k_denoise_ver<false, true, 0, true>), g2, block, l2, s, p, R, seg_rows); }
+        }
+        else if (!inf && p.verified && p.sh.nranks == 1 && p.extend == 0) {
             // the verified pass (exact output) or, with VRT_DENOISE_FAST, its cheap half alone: ONE round of workgroups, each a
             // 64-pixel column strip x seg_rows rows (four workgroups per compute unit fit)
             const int strips = (p.W + 63) / 64;
-            int per = 1024 / strips; if (per < 1) per = 1;            // (the literal evaluation at the end costs 115 VGPRs: four workgroups per compute unit)
+            int per = 1024 / strips; if (per < 1) per = 1;            // (four workgroups per compute unit, every unit the same number: the round ends together)
             int seg_rows = ((p.H + per - 1) / per + 3) & ~3; if (seg_rows < 8) seg_rows = 8;
             dim3 g2((unsigned)strips, (unsigned)((p.H + seg_rows - 1) / seg_rows));
             const int U = (4 + 2 * R + 3) / 4;
