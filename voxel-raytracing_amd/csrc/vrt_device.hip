@@ -1967,7 +1967,10 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
         const bool more = g + 1 < groups;
         if (more) fetch(g + U);                                  // the unit group g + 1 adds: in flight while group g is filtered
         const int yr = 4 * g + wave, py = ys + yr;               // relative row of the output; its taps' rows are yr, yr + R, yr + 2R in ring terms
-        if (py < ye && px < P.W) {
+        const bool have = py < ye && px < P.W;
+        uint32_t out_codes = 0u, out_idx = 0u;
+        bool out_sure = true;
+        if (have) {
             const int b0 = (yr % NR) * RW + lx, b1 = ((yr + R) % NR) * RW + lx, b2 = ((yr + 2 * R) % NR) * RW + lx;   // column of tap tx = -1
             uint2 sq; float4 sp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (PASS0) sq = make_uint2(lc[b1 + R], 0u); else { sq = lq[b1 + R]; sp = lp[b1 + R]; }
@@ -2018,10 +2021,15 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
             // sure <=> every channel's fraction lies further than the guard from 0 and from 1 (a NaN mean compares false)
             const bool sure = !FLAG || (__builtin_fabsf(f0 - 0.5f) < half_guard && __builtin_fabsf(f1 - 0.5f) < half_guard &&
                                         __builtin_fabsf(f2 - 0.5f) < half_guard && __builtin_fabsf(f3 - 0.5f) < half_guard);
-            if (sure) reinterpret_cast<uint32_t*>(P.color_out)[idx] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
-            else if (FLAG) { const uint32_t slot = atomicAdd(&fl_n, 1u); if (slot < VRT_DEN_FIXCAP) fl_px[slot] = idx; }
+            out_codes = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24); out_idx = idx; out_sure = sure;
         }
+        // (the ring first, the output after it: the wait for the fetched unit would otherwise also wait for this group's store
+        // -- on gfx950 one counter covers both -- once per group, with nothing left to hide it)
         if (more) stash(g + U);                                  // into the slots of the unit group g no longer reads
+        if (have) {
+            if (out_sure) reinterpret_cast<uint32_t*>(P.color_out)[out_idx] = out_codes;
+            else if (FLAG) { const uint32_t slot = atomicAdd(&fl_n, 1u); if (slot < VRT_DEN_FIXCAP) fl_px[slot] = out_idx; }
+        }
         __syncthreads();
     }
     if (FLAG) {
