@@ -202,3 +202,24 @@ def test_verified_pass_leaves_room(vrt, engine):
     print("guards", stage.guard(1), stage.guard(2), "redone", full, "with guard / 8", eighth, "of", W * H, "differing", int((got8 != lit).sum()))
     assert (got8 == lit).all(), int((got8 != lit).sum())
     assert all(0 < e < f for e, f in zip(eighth, full))
+
+
+def test_verified_pass_fourth_components_appear_late(vrt, oracle, engine):
+    """Colour alpha and position w are 0 in what K1 writes, and the rows of k_denoise_ver leave their sums out until a
+    texel with one enters the ring: a frame that has a single such texel far down a column strip, in each of the planes."""
+    import torch
+    W, H = 150, 230
+    rng = np.random.default_rng(77)
+    dev = engine.torch_device
+    for which in ("alpha", "w", "none"):
+        color = rng.integers(0, 256, (H, W, 4), dtype=np.uint8); color[..., 3] = 0
+        nrm = rng.choice(np.array([-127, 0, 90, 127], np.int8), (H, W, 4)); nrm[..., 3] = 0
+        pos = (np.round(rng.uniform(0, 32, (H, W, 4)) * 4) / 4).astype(np.float32); pos[..., 3] = 0.0
+        if which == "alpha": color[141, 70, 3] = 200
+        if which == "w": pos[171, 20, 3] = 0.5; pos[3, 3, 3] = -0.0
+        c, n, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (color, nrm, pos))
+        st = vrt.VoxelRenderSettings(targetResolution=(W, H))
+        st.denoiserSettings.iterations = 3
+        got = vrt.DenoiserStage(engine, st).record(c, n, p).cpu().numpy()
+        exp = oracle.denoise(color, nrm, pos, iterations=3)
+        assert (got == exp).all(), (which, int((got != exp).sum()))

@@ -1908,7 +1908,7 @@ template <bool SHIPPED, bool FLAG, int RT, bool PASS0 = false>
 __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int Rrt, int seg_rows)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
-    __shared__ uint32_t fl_n;
+    __shared__ uint32_t fl_n, fl_w4;
     __shared__ uint32_t fl_px[FLAG ? VRT_DEN_FIXCAP : 1];
     __shared__ float fx_w[FLAG ? 16 : 1][9];
     __shared__ uint32_t fx_c[FLAG ? 16 : 1][9];
@@ -1921,7 +1921,8 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     const int x0 = blockIdx.x * 64, ys = blockIdx.y * seg_rows;
     const int ye = ys + seg_rows < P.H ? ys + seg_rows : P.H;
     const int groups = (ye - ys + 3) >> 2;
-    if (FLAG && threadIdx.x == 0) fl_n = 0u;
+    if (threadIdx.x == 0) { fl_n = 0u; fl_w4 = 0u; }
+    __syncthreads();
     // a thread's two texels of a unit (4 * RW <= 512 of them): row in the unit, clamped frame column
     const int tA = (int)threadIdx.x, tB = tA + 256;
     const int rA = tA / RW, cA = tA - rA * RW, rB = tB / RW, cB = tB - rB * RW;
@@ -1951,6 +1952,8 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     };
     auto stash = [&](int unit) {
         const int slot = (unit % (U + 1)) * 4;
+        // (a colour alpha or a position w other than +-0: the rows take their general form from the next barrier on)
+        if (((colA | colB) >> 24) != 0u || ((__float_as_uint(pA.w) | __float_as_uint(pB.w)) << 1) != 0u) fl_w4 = 1u;
         if (PASS0) { lc[(slot + rA) * RW + cA] = colA; if (hasB) lc[(slot + rB) * RW + cB] = colB; return; }
         lp[(slot + rA) * RW + cA] = pA; lq[(slot + rA) * RW + cA] = make_uint2(colA, bias(nrmA));
         if (hasB) { lp[(slot + rB) * RW + cB] = pB; lq[(slot + rB) * RW + cB] = make_uint2(colB, bias(nrmB)); }
@@ -1963,6 +1966,67 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     constexpr int ntaps = SHIPPED ? 3 : 9;
     const float kc = P.vkc, kn = P.vkn, kp = P.vkp;
     const float half_guard = 0.5f - P.guard;
+    // One output row of a wave.  W4 = false: no texel in the ring has a colour alpha or a position w other than 0 (what K1 writes,
+    // SURVEY 9.4-F): the fourth channel's sums and the fourth difference are +0 whatever the weights are -- the same values
+    // without the instructions (a texel that has one raises fl_w4 when it is stored into the ring, before its first use).
+    auto row = [&](auto w4_tag, int yr, int py, uint32_t& out_codes, uint32_t& out_idx, bool& out_sure) {
+        constexpr bool W4 = decltype(w4_tag)::value;
+        const int b0 = (yr % NR) * RW + lx, b1 = ((yr + R) % NR) * RW + lx, b2 = ((yr + 2 * R) % NR) * RW + lx;   // column of tap tx = -1
+        uint2 sq; float4 sp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (PASS0) sq = make_uint2(lc[b1 + R], 0u); else { sq = lq[b1 + R]; sp = lp[b1 + R]; }
+        const uint32_t scc = PASS0 ? 0u : __builtin_amdgcn_udot4(sq.x, sq.x, 0u, false), snn = PASS0 ? 0u : __builtin_amdgcn_udot4(sq.y, sq.y, 0u, false);
+        constexpr float kcen = SHIPPED ? kGauss2 : kGauss0;
+        float a0 = (float)(sq.x & 0xFFu) * kcen, a1 = (float)((sq.x >> 8) & 0xFFu) * kcen, a2 = (float)((sq.x >> 16) & 0xFFu) * kcen, a3 = W4 ? (float)(sq.x >> 24) * kcen : 0.0f;
+        float total = kcen;
+#pragma unroll
+        for (int i = 0; i < ntaps; i++) {
+            int tx, ty;
+            if (SHIPPED) { tx = i == 0 ? -1 : (i == 1 ? 1 : 0); ty = i == 2 ? 0 : -1; }
+            else { tx = i % 3 - 1; ty = i / 3 - 1; }
+            if (tx == 0 && ty == 0) continue;                // the centre tap: every distance is 0, its weight is the kernel's (above)
+            const int ci = (ty < 0 ? b0 : (ty == 0 ? b1 : b2)) + (tx + 1) * R;
+            if (PASS0) {                                     // every edge-stopping weight is exactly 1: the tap's weight is the kernel's
+                const uint32_t oc = lc[ci];
+                const float kk = SHIPPED ? (i == 1 ? kGauss0 : kGauss2) : (r2_of(tx, ty) == 1 ? kGauss1 : kGauss2);
+                a0 = __builtin_fmaf((float)(oc & 0xFFu), kk, a0);
+                a1 = __builtin_fmaf((float)((oc >> 8) & 0xFFu), kk, a1);
+                a2 = __builtin_fmaf((float)((oc >> 16) & 0xFFu), kk, a2);
+                if (W4) a3 = __builtin_fmaf((float)(oc >> 24), kk, a3);
+                continue;
+            }
+            const uint2 oq = lq[ci];
+            const float4 op = lp[ci];
+            const int dc = mad24_minus2(__builtin_amdgcn_udot4(sq.x, oq.x, 0u, false), __builtin_amdgcn_udot4(oq.x, oq.x, scc, false));
+            const int dn = mad24_minus2(__builtin_amdgcn_udot4(sq.y, oq.y, 0u, false), __builtin_amdgcn_udot4(oq.y, oq.y, snn, false));
+            const float dx = sp.x - op.x, dy = sp.y - op.y, dz = sp.z - op.z;
+            float dp = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (W4) { const float dw = sp.w - op.w; dp = __builtin_fmaf(dw, dw, dp); }
+            // the kernel weight rides in the exponent: w * kern = exp2(-(e + -log2 kern))
+            const float lk = SHIPPED ? shipped_lk(i) : (r2_of(tx, ty) == 1 ? 0.18033688011112042f : 0.36067376022224085f);
+            const float e = __builtin_fmaf(dp, kp, __builtin_fmaf((float)dc, kc, __builtin_fmaf((float)dn, kn, lk)));
+            const float wk = __builtin_amdgcn_exp2f(-e);
+            a0 = __builtin_fmaf((float)(oq.x & 0xFFu), wk, a0);
+            a1 = __builtin_fmaf((float)((oq.x >> 8) & 0xFFu), wk, a1);
+            a2 = __builtin_fmaf((float)((oq.x >> 16) & 0xFFu), wk, a2);
+            if (W4) a3 = __builtin_fmaf((float)(oq.x >> 24), wk, a3);
+            total += wk;
+        }
+        // (PASS0: the weights' sum is a constant; its reciprocal rounded once from double)
+        const float r = PASS0 ? (SHIPPED ? (float)(1.0 / (2.0 * 0.7788007830714049 + 1.0)) : (float)(1.0 / (1.0 + 4.0 * 0.8824969025845955 + 4.0 * 0.7788007830714049))) : __builtin_amdgcn_rcpf(total);
+        // a weighted mean of codes, + 0.5: its floor is the output, its fraction says how far the nearest rounding boundary is
+        const float y0f = __builtin_fmaf(a0, r, 0.5f), y1f = __builtin_fmaf(a1, r, 0.5f), y2f = __builtin_fmaf(a2, r, 0.5f);
+        const float f0 = __builtin_amdgcn_fractf(y0f), f1 = __builtin_amdgcn_fractf(y1f), f2 = __builtin_amdgcn_fractf(y2f);
+        const uint32_t o0 = (uint32_t)fminf(y0f - f0, 255.0f), o1 = (uint32_t)fminf(y1f - f1, 255.0f), o2 = (uint32_t)fminf(y2f - f2, 255.0f);
+        // sure <=> every channel's fraction lies further than the guard from 0 and from 1 (a NaN mean compares false)
+        bool sure = !FLAG || (__builtin_fabsf(f0 - 0.5f) < half_guard && __builtin_fabsf(f1 - 0.5f) < half_guard && __builtin_fabsf(f2 - 0.5f) < half_guard);
+        uint32_t o3 = 0u;                                        // (W4 = false: the mean of zeros is 0, half a code from either boundary)
+        if (W4) {
+            const float y3f = __builtin_fmaf(a3, r, 0.5f), f3 = __builtin_amdgcn_fractf(y3f);
+            o3 = (uint32_t)fminf(y3f - f3, 255.0f);
+            if (FLAG) sure = sure && __builtin_fabsf(f3 - 0.5f) < half_guard;
+        }
+        out_codes = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24); out_idx = (uint32_t)py * (uint32_t)P.W + (uint32_t)px; out_sure = sure;
+    };
     for (int g = 0; g < groups; g++) {
         const bool more = g + 1 < groups;
         if (more) fetch(g + U);                                  // the unit group g + 1 adds: in flight while group g is filtered
@@ -1970,58 +2034,10 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
         const bool have = py < ye && px < P.W;
         uint32_t out_codes = 0u, out_idx = 0u;
         bool out_sure = true;
+        const bool w4 = fl_w4 != 0u;                             // (uniform: read after the barrier that follows every store into the ring)
         if (have) {
-            const int b0 = (yr % NR) * RW + lx, b1 = ((yr + R) % NR) * RW + lx, b2 = ((yr + 2 * R) % NR) * RW + lx;   // column of tap tx = -1
-            uint2 sq; float4 sp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (PASS0) sq = make_uint2(lc[b1 + R], 0u); else { sq = lq[b1 + R]; sp = lp[b1 + R]; }
-            const uint32_t scc = PASS0 ? 0u : __builtin_amdgcn_udot4(sq.x, sq.x, 0u, false), snn = PASS0 ? 0u : __builtin_amdgcn_udot4(sq.y, sq.y, 0u, false);
-            constexpr float kcen = SHIPPED ? kGauss2 : kGauss0;
-            float a0 = (float)(sq.x & 0xFFu) * kcen, a1 = (float)((sq.x >> 8) & 0xFFu) * kcen, a2 = (float)((sq.x >> 16) & 0xFFu) * kcen, a3 = (float)(sq.x >> 24) * kcen;
-            float total = kcen;
-#pragma unroll
-            for (int i = 0; i < ntaps; i++) {
-                int tx, ty;
-                if (SHIPPED) { tx = i == 0 ? -1 : (i == 1 ? 1 : 0); ty = i == 2 ? 0 : -1; }
-                else { tx = i % 3 - 1; ty = i / 3 - 1; }
-                if (tx == 0 && ty == 0) continue;                // the centre tap: every distance is 0, its weight is the kernel's (above)
-                const int ci = (ty < 0 ? b0 : (ty == 0 ? b1 : b2)) + (tx + 1) * R;
-                if (PASS0) {                                     // every edge-stopping weight is exactly 1: the tap's weight is the kernel's
-                    const uint32_t oc = lc[ci];
-                    const float kk = SHIPPED ? (i == 1 ? kGauss0 : kGauss2) : (r2_of(tx, ty) == 1 ? kGauss1 : kGauss2);
-                    a0 = __builtin_fmaf((float)(oc & 0xFFu), kk, a0);
-                    a1 = __builtin_fmaf((float)((oc >> 8) & 0xFFu), kk, a1);
-                    a2 = __builtin_fmaf((float)((oc >> 16) & 0xFFu), kk, a2);
-                    a3 = __builtin_fmaf((float)(oc >> 24), kk, a3);
-                    continue;
-                }
-                const uint2 oq = lq[ci];
-                const float4 op = lp[ci];
-                // (u - 2 v as one 24-bit multiply-add: both are below 2^19)
-                const int dc = mad24_minus2(__builtin_amdgcn_udot4(sq.x, oq.x, 0u, false), __builtin_amdgcn_udot4(oq.x, oq.x, scc, false));
-                const int dn = mad24_minus2(__builtin_amdgcn_udot4(sq.y, oq.y, 0u, false), __builtin_amdgcn_udot4(oq.y, oq.y, snn, false));
-                const float dx = sp.x - op.x, dy = sp.y - op.y, dz = sp.z - op.z, dw = sp.w - op.w;
-                const float dp = __builtin_fmaf(dw, dw, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
-                // the kernel weight rides in the exponent: w * kern = exp2(-(e + -log2 kern))
-                const float lk = SHIPPED ? shipped_lk(i) : (r2_of(tx, ty) == 1 ? 0.18033688011112042f : 0.36067376022224085f);
-                const float e = __builtin_fmaf(dp, kp, __builtin_fmaf((float)dc, kc, __builtin_fmaf((float)dn, kn, lk)));
-                const float wk = __builtin_amdgcn_exp2f(-e);
-                a0 = __builtin_fmaf((float)(oq.x & 0xFFu), wk, a0);
-                a1 = __builtin_fmaf((float)((oq.x >> 8) & 0xFFu), wk, a1);
-                a2 = __builtin_fmaf((float)((oq.x >> 16) & 0xFFu), wk, a2);
-                a3 = __builtin_fmaf((float)(oq.x >> 24), wk, a3);
-                total += wk;
-            }
-            // (PASS0: the weights' sum is a constant; its reciprocal rounded once from double)
-            const float r = PASS0 ? (SHIPPED ? (float)(1.0 / (2.0 * 0.7788007830714049 + 1.0)) : (float)(1.0 / (1.0 + 4.0 * 0.8824969025845955 + 4.0 * 0.7788007830714049))) : __builtin_amdgcn_rcpf(total);
-            // a weighted mean of codes, + 0.5: its floor is the output, its fraction says how far the nearest rounding boundary is
-            const float y0f = __builtin_fmaf(a0, r, 0.5f), y1f = __builtin_fmaf(a1, r, 0.5f), y2f = __builtin_fmaf(a2, r, 0.5f), y3f = __builtin_fmaf(a3, r, 0.5f);
-            const float f0 = __builtin_amdgcn_fractf(y0f), f1 = __builtin_amdgcn_fractf(y1f), f2 = __builtin_amdgcn_fractf(y2f), f3 = __builtin_amdgcn_fractf(y3f);
-            const uint32_t o0 = (uint32_t)fminf(y0f - f0, 255.0f), o1 = (uint32_t)fminf(y1f - f1, 255.0f), o2 = (uint32_t)fminf(y2f - f2, 255.0f), o3 = (uint32_t)fminf(y3f - f3, 255.0f);
-            const uint32_t idx = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
-            // sure <=> every channel's fraction lies further than the guard from 0 and from 1 (a NaN mean compares false)
-            const bool sure = !FLAG || (__builtin_fabsf(f0 - 0.5f) < half_guard && __builtin_fabsf(f1 - 0.5f) < half_guard &&
-                                        __builtin_fabsf(f2 - 0.5f) < half_guard && __builtin_fabsf(f3 - 0.5f) < half_guard);
-            out_codes = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24); out_idx = idx; out_sure = sure;
+            if (w4) row(std::true_type{}, yr, py, out_codes, out_idx, out_sure);
+            else    row(std::false_type{}, yr, py, out_codes, out_idx, out_sure);
         }
         // (the ring first, the output after it: the wait for the fetched unit would otherwise also wait for this group's store
         // -- on gfx950 one counter covers both -- once per group, with nothing left to hide it)
