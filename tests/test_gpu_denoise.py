@@ -141,7 +141,7 @@ def _hostile_gbuffer(rng, W, H):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("size", [(200, 120), (333, 61), (64, 8), (70, 13)])
+@pytest.mark.parametrize("size", [(200, 120), (333, 61), (64, 8), (70, 13), (1, 1), (5, 3), (130, 2)])
 def test_verified_pass_is_the_literal_pass(vrt, oracle, engine, mode, size):
     import torch
     W, H = size
@@ -169,7 +169,7 @@ def test_verified_pass_is_the_literal_pass(vrt, oracle, engine, mode, size):
         exp = oracle.denoise(color, nrm, pos, iterations=iterations, step_width0=step, mode=mode, **kw)
         assert (lit == exp).all()
         assert (got == exp).all(), (iterations, step, int((got != exp).sum()))
-        assert max(redone) < W * H // 4 and (redone[1] > 0 or W * H < 10000), redone                  # a few per cent are redone
+        assert W * H < 10000 or (max(redone) < W * H // 4 and redone[1] > 0), redone                  # a few per cent are redone
 
 
 def test_verified_pass_leaves_room(vrt, engine):
