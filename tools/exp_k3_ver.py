@@ -32,3 +32,13 @@ for iters in (1, 2, 3):
     t_fold, d, _ = run(iters, vrt.DENOISE_FAST, 0)
     print(f"iterations {iters}: exact {t_ex*1e3:.1f} us  verified {t_ver*1e3:.1f} us (redone {red}, equal {bool((a == b).all())})  "
           f"fast(new) {t_fast*1e3:.1f} us (max diff {int(np.abs(a.astype(int) - c.astype(int)).max())})  fast(old) {t_fold*1e3:.1f} us (max diff {int(np.abs(a.astype(int) - d.astype(int)).max())})", flush=True)
+# back to back: 40 calls without a synchronisation in between (the kernel-trace shows whether a lone call pays for a cold start)
+st.denoiserSettings.iterations = 2; st.denoiserSettings.mode = 0; eng.set_option("denoise_verified", 1)
+den = vrt.DenoiserStage(eng, st)
+import time
+for rep in range(3):
+    eng.synchronize(); t0 = time.perf_counter()
+    for _ in range(40):
+        den.record(gb.color, gb.normal, gb.position)
+    eng.synchronize(); t1 = time.perf_counter()
+    print(f"40 calls back to back: {(t1 - t0) / 40 * 1e6:.1f} us per call (two passes)", flush=True)

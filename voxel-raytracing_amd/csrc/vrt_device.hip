@@ -1958,7 +1958,15 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
         lp[(slot + rA) * RW + cA] = pA; lq[(slot + rA) * RW + cA] = make_uint2(colA, bias(nrmA));
         if (hasB) { lp[(slot + rB) * RW + cB] = pB; lq[(slot + rB) * RW + cB] = make_uint2(colB, bias(nrmB)); }
     };
-    for (int u = 0; u < U; u++) { fetch(u); stash(u); }
+    {
+        // the first U units (U <= 4), all requested before the first is stored: one round trip to memory, not U (every workgroup
+        // of the launch stands here at the same time: nothing else hides them)
+        float4 qpA[4], qpB[4]; uint32_t qcA[4], qnA[4], qcB[4], qnB[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (u < U) { fetch(u); qpA[u] = pA; qpB[u] = pB; qcA[u] = colA; qnA[u] = nrmA; qcB[u] = colB; qnB[u] = nrmB; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (u < U) { pA = qpA[u]; pB = qpB[u]; colA = qcA[u]; nrmA = qnA[u]; colB = qcB[u]; nrmB = qnB[u]; stash(u); }
+    }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2142,7 +2150,7 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
             // the verified pass (exact output) or, with VRT_DENOISE_FAST, its cheap half alone: ONE round of workgroups, each a
             // 64-pixel column strip x seg_rows rows (four workgroups per compute unit fit)
             const int strips = (p.W + 63) / 64;
-            int per = 1024 / strips; if (per < 1) per = 1;            // (four workgroups per compute unit, every unit the same number: the round ends together)
+            int per = 1024 / strips; if (per < 1) per = 1;            // (about four workgroups per compute unit; 768 ... 2048 measured the same)
             int seg_rows = ((p.H + per - 1) / per + 3) & ~3; if (seg_rows < 8) seg_rows = 8;
             dim3 g2((unsigned)strips, (unsigned)((p.H + seg_rows - 1) / seg_rows));
             const int U = (4 + 2 * R + 3) / 4;
