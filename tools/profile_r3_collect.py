@@ -60,9 +60,10 @@ print("K1:", {k: round(v["mean_per_launch"] / fpl / 1e6, 3) for k, v in k1.items
 sets = {
     "r03_megakernel_pmc.json": ("k_primary<7, false, 4 (megakernel; the scene has no metallic voxel, so the form without the bounce loop)>: config 3 (shadow ray; launches 1-20) and the reference defaults (AO 4, shadow, <= 5 bounces; launches 21-30), 1080p, one frame per launch",
                                 lambda n: "k_primary<7" in n and (", 2, false" in n or ", 4, false" in n)),
-    "r03_k_denoise_pmc.json": ("k_denoise_lds<false, false, false, true> (exact weighted pass, two taps at a time in packed fp32), 1080p", lambda n: "k_denoise_lds<false, false, false, true>" in n),
-    "r03_k_denoise_fast_pmc.json": ("k_denoise_fast<false, 8> (VRT_DENOISE_FAST weighted pass), 1080p", lambda n: "k_denoise_fast" in n),
-    "r03_k_denoise_pass0_pmc.json": ("k_denoise_lds<true, false> (pass 0: plain blur), 1080p", lambda n: "k_denoise_lds<true" in n),
+    "r03_k_denoise_pmc.json": ("k_denoise_ver<false, true, 3, false> (the verified weighted pass: exact output, the default), 1080p", lambda n: "k_denoise_ver<false, true, 3, false>" in n),
+    "r03_k_denoise_fast_pmc.json": ("k_denoise_ver<false, false, 3, false> (VRT_DENOISE_FAST weighted pass: the verified pass' cheap half alone), 1080p", lambda n: "k_denoise_ver<false, false, 3, false>" in n),
+    "r03_k_denoise_pass0_pmc.json": ("k_denoise_ver<false, true, 1, true> (pass 0: plain blur, verified form), 1080p", lambda n: "k_denoise_ver<false, true, 1, true>" in n),
+    "r03_k_denoise_exact_pmc.json": ("k_denoise_lds<false, false, false, true> (the exact weighted pass computing every pixel, context option denoise_verified = 0: what the verified pass replaced), 1080p", lambda n: "k_denoise_lds<false, false, false, true>" in n),
     "r03_mandelbulb_pmc.json": ("k_primary<7, false, 2 (megakernel)>: BASELINE configs[3], Mandelbulb 512^3, 3840x2160, 2 bounces, AO 4, shadow ray, one frame per launch (the last five launches of the run; the counters below average ALL launches of the megakernel with the bounce loop, of which the 1080p reference defaults are the first ten)",
                                 lambda n: "k_primary<7" in n and ", 2, false" in n),
     "r03_brick_pmc.json": ("k_primary<6 (BRICK), false, 2 (megakernel)>: BASELINE configs[4], 2048^3 brick scene, 3840x2160, max_steps 6144, 4 bounces, AO 4, one frame per launch",

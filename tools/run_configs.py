@@ -1,5 +1,5 @@
 """The secondary-ray and brick configurations as a plain frame loop for rocprofv3 (tools/profile_r2.sh): config 3 (shadow ray, 2
-denoiser passes, exact and VRT_DENOISE_FAST), the reference defaults (AO 4, shadow, <= 5 bounces), and BASELINE configs[4]
+denoiser passes: the verified pair, VRT_DENOISE_FAST, and the exact kernels computing every pixel), the reference defaults (AO 4, shadow, <= 5 bounces), and BASELINE configs[4]
 (2048^3 brick scene at 3840x2160) -- 10 frames each, the device idle between frames."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,6 +25,9 @@ def loop(scene, res, dims, ao, bounces, iters, mode, max_steps, pos, n=10):
     print(res, ao, bounces, iters, mode, eng.last_timings(), flush=True)
 loop(sc, (1920, 1080), 256, 0, 0, 2, 0, 512, (128.0, 128.0, -204.8))
 loop(sc, (1920, 1080), 256, 0, 0, 2, vrt.DENOISE_FAST, 512, (128.0, 128.0, -204.8))
+eng.set_option("denoise_verified", 0)                    # the exact kernels computing every pixel (what the verified pass replaced)
+loop(sc, (1920, 1080), 256, 0, 0, 2, 0, 512, (128.0, 128.0, -204.8))
+eng.set_option("denoise_verified", 1)
 loop(sc, (1920, 1080), 256, 4, 5, 2, 0, 512, (128.0, 128.0, -204.8))
 grid, pool = vrt.synthetic.sparse_brick_scene(2048, 0.015, seed=5)
 sb = vrt.VoxelScene.from_bricks(eng, grid, pool, pal, sky=sky, noise=noise)
