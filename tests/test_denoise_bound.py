@@ -67,7 +67,7 @@ def _guard_here(phi_c, phi_n, phi_p, sw, shipped, c1c, c1n, ex):
     An = sw * sw * phi_n
     alpha = 0.8578 * (c1c / math.sqrt(phi_c) + c1n / math.sqrt(An)) + 0.3679 * (4.02 + 5.03 + 7.05) * EPS
     spec = (3 * ex + 2 * EPS) + alpha * K / kcen + 21.3 * EPS
-    fast = 2 * EPS + n * 2.962 * EPS / kcen + 19 * EPS
+    fast = 4 * EPS + n * 2.962 * EPS / kcen + 19 * EPS
     return 255.0 * (spec + fast) + 767 * EPS
 
 

@@ -37,10 +37,11 @@
 //     lk = RN(-log2 kappa): |e - e*| <= 8.05 eps e*, where kappa w = 2^-e*.  v_exp_f32 and v_rcp_f32 are accurate to 1 ulp
 //     (<= 2 eps relative); x 2^-x <= 0.5307:
 //         | W - kappa w |  <=  2 eps kappa w + 0.6931 * 8.05 * 0.5307 eps  =  2 eps kappa w + 2.962 eps     (+ 1e-37 flushed)
-//     and  | R(W) - R | <= 2 eps + n_taps' * 2.962 eps / kappa_centre.  Sums: the centre term (one rounding unless kappa = 1), eight
+//     -- and 2 eps more: the exponent's constant is -log2 of the Gaussian itself, the spec's kappa that Gaussian rounded to fp32 --
+//     and  | R(W) - R | <= 4 eps + n_taps' * 2.962 eps / kappa_centre.  Sums: the centre term (one rounding unless kappa = 1), eight
 //     fused accumulations, eight additions of the total, the reciprocal 2 eps: 19 eps relative; fma(sum, r, 0.5): 256 eps codes.
 //
-// guard = 1.01 * 255 * [ (3 EX + 2 eps) + ALPHA_S K / kc + 21.3 eps  +  2 eps + n 2.962 eps / kc + 19 eps ] + 767 eps.
+// guard = 1.01 * 255 * [ (3 EX + 2 eps) + ALPHA_S K / kc + 21.3 eps  +  4 eps + n 2.962 eps / kc + 19 eps ] + 767 eps.
 // At the reference's defaults (pass 1: phi 20.4 / 0.01 / 0.1, stepWidth 3) it is 3.2e-3 of a code: about 2 % of the pixels of
 // a frame are redone.  Non-finite positions make the cheap mean NaN, which fails the guard's comparison: redone too.
 #pragma once
@@ -68,17 +69,18 @@ inline double denoise_guard(double phi_color, double phi_normal, double phi_pos,
     const double An = step_width * step_width * phi_normal;
     const double alpha_s = 0.8578 * (kDenC1Color / std::sqrt(phi_color) + kDenC1Normal / std::sqrt(An)) + 0.3679 * (4.02 + 5.03 + 7.05) * eps + 1e-37;
     const double spec = (3.0 * kDenExpSpec + 2.0 * eps) + alpha_s * K / kcen + 21.3 * eps;
-    const double fast = 2.0 * eps + n * (2.962 * eps + 1e-37) / kcen + 19.0 * eps;
+    const double fast = 4.0 * eps + n * (2.962 * eps + 1e-37) / kcen + 19.0 * eps;
     return 1.01 * 255.0 * (spec + fast) + 767.0 * eps;
 }
 
 // Pass 0 (phi = +inf: every edge-stopping weight is exactly 1, the pass is a plain 3 x 3 blur; tap offset 1).  The spec: a term
 // RN(RN(c / 255) kappa) carries 2 eps, eight additions 8 eps, the total's eight additions 8 eps, the quotient 1 eps: 19.2 eps
 // relative on a value <= 1, then 511 eps codes of the two final roundings.  The cheap form: nine fused accumulations of
-// code * kappa, the reciprocal of the weights' sum rounded once from double, one fused multiply-add: 10.1 eps relative, 256 eps.
+// code * kappa, the reciprocal of the weights' sum rounded once from double (the sum of the Gaussians themselves: within 2 eps
+// of the sum of the spec's fp32 constants), one fused multiply-add: 12.1 eps relative, 256 eps.
 inline double denoise_guard_pass0()
 {
-    return 1.01 * 255.0 * (19.2 + 10.1) * kDenEps + 767.0 * kDenEps;
+    return 1.01 * 255.0 * (19.2 + 12.1) * kDenEps + 767.0 * kDenEps;
 }
 
 } // namespace vrt
