@@ -51,7 +51,7 @@ STORE_GBS = 6100.0             # what plain stores reach on this part (same guid
 B_OUT = 37                     # bytes stored per pixel: the reference's 6-target G-buffer (geometry_stage.cpp:22-33)
 K3_BYTES_PASS0 = 8             # denoiser pass 0 (phi = +inf): colour in + colour out
 K3_BYTES_PASS = 28             # weighted pass: colour + normal + position in (4 + 4 + 16), colour out
-KERNEL_SOURCES = ("vrt_device.hip", "vrt_traverse.h", "vrt_spec.h", "vrt_sky.h", "vrt_tags.h", "vrt_internal.h", "vrt_api.hip", "Makefile")
+KERNEL_SOURCES = ("vrt_device.hip", "vrt_traverse.h", "vrt_spec.h", "vrt_sky.h", "vrt_tags.h", "vrt_denoise_bound.h", "vrt_internal.h", "vrt_api.hip", "Makefile")
 
 
 def log(*a):

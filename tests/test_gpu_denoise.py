@@ -223,3 +223,10 @@ def test_verified_pass_fourth_components_appear_late(vrt, oracle, engine):
         got = vrt.DenoiserStage(engine, st).record(c, n, p).cpu().numpy()
         exp = oracle.denoise(color, nrm, pos, iterations=3)
         assert (got == exp).all(), (which, int((got != exp).sum()))
+
+
+def test_verified_pass_fuzz_sweep(vrt, oracle, engine):
+    """60 random cases of tests/fuzz_denoise.py (sizes, phis over the admitted range, step widths, modes, pass counts, G-buffer kinds)."""
+    import fuzz_denoise
+    verified, redone = fuzz_denoise.run(vrt, oracle, engine, 60, seed=2026)
+    assert verified > 40                                    # most passes of the sweep do take the verified form
