@@ -144,8 +144,9 @@ int  vrt_ctx_set_stream(vrt_ctx* ctx, void* hip_stream);
 int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle(), engine.cpp:351 */
 /* Development switches of a context (no reference analogue; the reference's counterpart is recompiling a shader): every
  * one is 1 by default and changes speed only, never a result -- the tests render "the same frame without X" with them.
- * Names: "tile_tags", "box_rect", "xcd_regions", "fast_loop", "no_bounce_kernel", "sky_fast" (looked at by every
- * vrt_render_geometry* call), "denoise_th16", "denoise_packed" (by vrt_denoise) and "open_cells", "df_prefetch", "df_own"
+ * Names: "tile_tags", "box_rect", "xcd_regions", "fast_loop", "thresh_runs", "hit_table", "no_bounce_kernel", "sky_fast" (looked at by every
+ * vrt_render_geometry* call), "denoise_th16", "denoise_packed", "denoise_verified" (by vrt_denoise; "denoise_guard_div8" and
+ * "denoise_count", both 0 by default, are the tests' handles on the verified pass) and "open_cells", "df_prefetch", "df_own"
  * (looked at when a scene is created).  The
  * environment seeds them ONCE, at vrt_ctx_create (VRT_TILE_TAGS=0, VRT_SKY_FAST=0, ...); nothing on the render path
  * calls getenv.  Unknown name: VRT_ERR_INVALID. */

@@ -230,3 +230,28 @@ def test_verified_pass_fuzz_sweep(vrt, oracle, engine):
     import fuzz_denoise
     verified, redone = fuzz_denoise.run(vrt, oracle, engine, 60, seed=2026)
     assert verified > 40                                    # most passes of the sweep do take the verified form
+
+
+def test_verified_pass_when_every_pixel_is_redone(vrt, oracle, engine):
+    """NaN positions everywhere: the cheap mean of every pixel is NaN, the list of a workgroup overflows (1 024 entries for 64 x 32
+    pixels) and the workgroup evaluates its whole segment literally."""
+    import torch
+    W, H = 190, 90
+    rng = np.random.default_rng(3)
+    color = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    nrm = rng.choice(np.array([-127, 0, 127], np.int8), (H, W, 4))
+    pos = np.full((H, W, 4), np.nan, np.float32)
+    dev = engine.torch_device
+    c, n, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (color, nrm, pos))
+    for mode in (0, 1):
+        st = vrt.VoxelRenderSettings(targetResolution=(W, H))
+        st.denoiserSettings.iterations = 3; st.denoiserSettings.mode = mode
+        stage = vrt.DenoiserStage(engine, st)
+        engine.set_option("denoise_count", 1)
+        try:
+            got = stage.record(c, n, p).cpu().numpy()
+            assert stage.redone(1) == W * H and stage.redone(2) == W * H
+        finally:
+            engine.set_option("denoise_count", 0)
+        exp = oracle.denoise(color, nrm, pos, iterations=3, mode=mode)
+        assert (got == exp).all(), int((got != exp).sum())
