@@ -1,0 +1,39 @@
+"""Where a weighted denoiser pass spends its 27 us (development build: make -C voxel-raytracing_amd/csrc variant NAME=k3st
+EXTRA=-DVRT_K3_STAMPS; VRT_LIB=.../libvrt_hip_k3st.so): every workgroup of k_denoise_ver leaves its start / ring filled / rows done /
+end stamps (100 MHz) in the first words of the output image."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import voxel_raytracing_amd as vrt
+from helpers import camera_push
+eng = vrt.Engine(0)
+pal = vrt.synthetic.default_palette(metallic_ids=range(200, 256))
+sc = vrt.VoxelScene.from_dense(eng, vrt.synthetic.treehouse(256, seed=2), pal, sky=vrt.synthetic.sky_gradient(512, 256), noise=vrt.synthetic.blue_noise_standin(512))
+res = (1920, 1080)
+st = vrt.VoxelRenderSettings(targetResolution=res); st.fsrSetttings.enable = False; st.occlusionSettings.numSamples = 0
+gb = vrt.GeometryStage(eng, st, sc).record(camera_push(vrt, (256, 256, 256), res)); eng.synchronize()
+st.denoiserSettings.iterations = 2
+den = vrt.DenoiserStage(eng, st)
+for rep in range(4):
+    out = den.record(gb.color, gb.normal, gb.position); eng.synchronize()
+n = 30 * 34
+w = out.cpu().numpy().view(np.uint32).reshape(-1)[: 4 * n].reshape(n, 4).astype(np.int64)
+t0 = w[:, 0].min()
+w = (w - t0) / 100.0                                       # us
+print("workgroups", n, "kernel span %.1f us" % (w[:, 3].max()))
+for name, col in (("start", 0), ("ring filled", 1), ("rows done", 2), ("end", 3)):
+    v = np.sort(w[:, col]); print(f"{name:12s}: min {v[0]:.1f}  10% {v[n//10]:.1f}  median {v[n//2]:.1f}  90% {v[9*n//10]:.1f}  max {v[-1]:.1f}")
+print("prologue (ring filled - start): median %.1f max %.1f;  rows: median %.1f max %.1f;  tail: median %.1f max %.1f" % (
+      np.median(w[:, 1] - w[:, 0]), (w[:, 1] - w[:, 0]).max(), np.median(w[:, 2] - w[:, 1]), (w[:, 2] - w[:, 1]).max(), np.median(w[:, 3] - w[:, 2]), (w[:, 3] - w[:, 2]).max()))
+
+ok = np.abs(w[:, 0] - np.median(w[:, 0])) < 2.0              # (stamps of a few workgroups are overwritten by pixels of the first rows)
+ok &= (w[:, 3] > w[:, 0]) & (w[:, 3] < w[:, 0] + 100)
+rows = w[:, 2] - w[:, 1]; life = w[:, 3] - w[:, 0]
+gx, gy = 30, n // 30
+ids = np.arange(n); bx, by = ids % gx, ids // gx
+print("usable", int(ok.sum()), "of", n)
+print("life by wg_id % 8 (XCD):", [round(float(np.median(life[ok & (ids % 8 == k)])), 1) for k in range(8)])
+print("life by segment row (0..33):", [round(float(np.median(life[ok & (by == k)])), 1) for k in range(gy)])
+print("life by strip (0..29):", [round(float(np.median(life[ok & (bx == k)])), 1) for k in range(gx)])
+print("life by (wg_id // 8) % 32 (CU within XCD?):", [round(float(np.median(life[ok & ((ids // 8) % 32 == k)])), 1) for k in range(32)])

@@ -1912,6 +1912,17 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     __shared__ uint32_t fl_px[FLAG ? VRT_DEN_FIXCAP : 1];
     __shared__ float fx_w[FLAG ? 16 : 1][9];
     __shared__ uint32_t fx_c[FLAG ? 16 : 1][9];
+#ifdef VRT_K3_STAMPS
+    // (development build, tools/exp_k3_timeline.py: a workgroup's start / ring filled / rows done / end on the 100 MHz clock, written
+    // over the first words of color_out when it ends -- the image is garbage)
+    uint32_t k3_t[4] = {(uint32_t)wall_clock64(), 0u, 0u, 0u};
+    auto k3_stamp = [&]() {
+        if (threadIdx.x == 0) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(P.color_out) + 4u * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = k3_t[0]; o[1] = k3_t[1]; o[2] = k3_t[2]; o[3] = (uint32_t)wall_clock64();
+        }
+    };
+#endif
     const int R = RT ? RT : Rrt;
     const int RW = 64 + 2 * R;
     const int U = (4 + 2 * R + 3) / 4;                    // units of four rows a group of four output rows reads
@@ -1969,6 +1980,9 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     }
     __syncthreads();
 
+#ifdef VRT_K3_STAMPS
+    k3_t[1] = (uint32_t)wall_clock64();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lx = threadIdx.x & 63, px = x0 + lx;
     constexpr int ntaps = SHIPPED ? 3 : 9;
@@ -2056,9 +2070,15 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
         }
         __syncthreads();
     }
+#ifdef VRT_K3_STAMPS
+    k3_t[2] = (uint32_t)wall_clock64();
+#endif
     if (FLAG) {
         // (the loop's last barrier is behind us: fl_n and fl_px are final)
         const uint32_t n = fl_n;
+#ifdef VRT_K3_STAMPS
+        if (n == 0u) { __syncthreads(); k3_stamp(); return; }
+#endif
         if (n == 0u) return;                                     // uniform per workgroup
         if (P.fix_counts && threadIdx.x == 0) atomicAdd(&P.fix_counts[(blockIdx.y * gridDim.x + blockIdx.x) & (VRT_DENOISE_SEGS - 1u)], n);
         {
@@ -2115,6 +2135,9 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
             }
         }
     }
+#ifdef VRT_K3_STAMPS
+    __syncthreads(); k3_stamp();
+#endif
 }
 
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
