@@ -52,7 +52,8 @@ def test_sharded_trace_assembles_to_full_frame(vrt, engine, nranks, strip_rows):
 # pass at a reach of 1; 2.5 takes the untiled bilinear kernel
 @pytest.mark.parametrize("nranks,strip_rows,iters,step_width", [(2, 16, 2, 2.0), (3, 16, 2, 2.0), (4, 32, 3, 2.0),
                                                                 (2, 16, 2, 1.0), (3, 16, 2, 1.0), (2, 16, 2, 5.0), (3, 16, 2, 5.0),
-                                                                (2, 16, 3, 0.0), (3, 16, 3, 1.0), (2, 16, 2, 2.5)])
+                                                                (2, 16, 3, 0.0), (3, 16, 3, 1.0), (2, 16, 2, 2.5),
+                                                                (3, 48, 3, 2.0), (2, 80, 2, 2.0), (5, 32, 2, 2.0)])       # one band per rank
 def test_sharded_denoise_with_halo(vrt, engine, nranks, strip_rows, iters, step_width):
     res = (96, 130)
     sc, st = _setup(vrt, engine, res, True)

@@ -1195,13 +1195,13 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
     p.tile16 = c->opt.denoise_th16; p.no_packed = c->opt.denoise_packed ? 0 : 1;
     uint8_t* targets[2] = {target0, target1};
     const uint8_t* last = color_in;
-    // which passes take the verified form (whole frame on one rank, a weighted pass, an integral tap offset, a guard worth having)
+    // which passes take the verified form (an integral tap offset, a guard worth having)
     double guards[10];
     bool any_verified = false;
     c->den_last_passes = 0;
     for (int i = 0; i < ds->iterations; i++) {
         guards[i] = INFINITY;
-        if (!c->opt.denoise_verified || p.sh.nranks != 1 || (size_t)W * (size_t)H >= (1u << 28)) continue;
+        if (!c->opt.denoise_verified || (size_t)W * (size_t)H >= (1u << 28)) continue;
         if (i == 0) { guards[0] = denoise_guard_pass0(); any_verified = true; continue; }      // pass 0: a plain blur, tap offset 1
         const float inv = 1.0f / (float)i;                     // the pass' parameters as the loop below makes them
         guards[i] = denoise_guard((double)(inv * ds->phi_color0), (double)(inv * ds->phi_normal0), (double)(inv * ds->phi_pos0),

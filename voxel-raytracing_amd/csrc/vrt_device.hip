@@ -1905,7 +1905,7 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
 // asm block here read stale registers; the compiler's own 24-bit multiply-add sign-extends first and is three instructions.
 __device__ __forceinline__ int mad24_minus2(uint32_t v, uint32_t u) { return (int)(u - 2u * v); }
 template <bool SHIPPED, bool FLAG, int RT, bool PASS0 = false>
-__global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int Rrt, int seg_rows)
+__global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int Rrt, int seg_rows, int segs_per_strip)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
     __shared__ uint32_t fl_n, fl_w4;
@@ -1929,8 +1929,20 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     const int NR = 4 * (U + 1);                           // ring: those + the unit on its way in
     float4* lp = lds_g; uint2* lq = reinterpret_cast<uint2*>(lds_g + NR * RW);
     uint32_t* lc = reinterpret_cast<uint32_t*>(lds_g);      // PASS0 (phi = +inf, every weight exactly 1): the ring holds the colour codes only
-    const int x0 = blockIdx.x * 64, ys = blockIdx.y * seg_rows;
-    const int ye = ys + seg_rows < P.H ? ys + seg_rows : P.H;
+    // the rows of this workgroup: segment j of the rank's local strip k, the strip taken with the `extend` rows either side that
+    // this pass must also produce (strip_row's rows; one rank: the one strip is the frame)
+    const int x0 = blockIdx.x * 64;
+    int ys, ye;
+    {
+        const int k = (int)blockIdx.y / segs_per_strip, j = (int)blockIdx.y - k * segs_per_strip;
+        const int g = k * P.sh.nranks + P.sh.rank;
+        int r0 = g * P.sh.strip_rows - P.extend, r1 = (g + 1) * P.sh.strip_rows;
+        r1 = (r1 < P.H ? r1 : P.H) + P.extend;
+        r0 = r0 < 0 ? 0 : r0; r1 = r1 < P.H ? r1 : P.H;
+        ys = r0 + j * seg_rows;
+        ye = ys + seg_rows < r1 ? ys + seg_rows : r1;
+    }
+    if (ys >= ye) return;                                 // uniform per workgroup (a strip's last segment may be empty)
     const int groups = (ye - ys + 3) >> 2;
     if (threadIdx.x == 0) { fl_n = 0u; fl_w4 = 0u; }
     __syncthreads();
@@ -2152,44 +2164,42 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     float sw = p.step_width;
     int R = (int)sw;
     bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
-    if (tiled) {
-        size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * (inf ? 16 : 48);   // pass 0 stages the colour plane only
-        const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
-        if (inf && p.verified && p.sh.nranks == 1 && p.extend == 0 && !(p.mode & VRT_DENOISE_FAST)) {
-            // pass 0 the same way: the ring holds the colour plane only, the weights are the kernel's
-            // (34 VGPRs and 9 KB of LDS: eight workgroups per compute unit, whose groups of rows hide each other's fetches)
-            const int strips = (p.W + 63) / 64;
-            int per = 2048 / strips; if (per < 1) per = 1;
-            int seg_rows = ((p.H + per - 1) / per + 3) & ~3; if (seg_rows < 8) seg_rows = 8;
-            dim3 g2((unsigned)strips, (unsigned)((p.H + seg_rows - 1) / seg_rows));
-            const int U = (4 + 2 * R + 3) / 4;
-            const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(4 * (U + 1)) * 4;
-            if (R == 1) { if (shipped) hipLaunchKernelGGL((k_denoise_ver<true, true, 1, true>), g2, block, l2, s, p, R, seg_rows);
-                          else         hipLaunchKernelGGL((k_denoise_ver<false, true, 1, true>), g2, block, l2, s, p, R, seg_rows); }
-            else        { if (shipped) hipLaunchKernelGGL((k_denoise_ver<true, true, 0, true>), g2, block, l2, s, p, R, seg_rows);
-                          else         hipLaunchKernelGGL((k_denoise_ver<false, true, 0, true>), g2, block, l2, s, p, R, seg_rows); }
-        }
-        else if (!inf && p.verified && p.sh.nranks == 1 && p.extend == 0) {
-            // the verified pass (exact output) or, with VRT_DENOISE_FAST, its cheap half alone: ONE round of workgroups, each a
-            // 64-pixel column strip x seg_rows rows (four workgroups per compute unit fit)
-            const int strips = (p.W + 63) / 64;
-            int per = 1024 / strips; if (per < 1) per = 1;            // (about four workgroups per compute unit; 768 ... 2048 measured the same)
-            int seg_rows = ((p.H + per - 1) / per + 3) & ~3; if (seg_rows < 8) seg_rows = 8;
-            dim3 g2((unsigned)strips, (unsigned)((p.H + seg_rows - 1) / seg_rows));
-            const int U = (4 + 2 * R + 3) / 4;
-            const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(4 * (U + 1)) * 24;
+    const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
+    if ((float)R == sw && R >= 1 && R <= 5 && p.verified && !(inf && (p.mode & VRT_DENOISE_FAST))) {
+        // the verified pass (exact output) or, with VRT_DENOISE_FAST, its cheap half alone: 64-pixel column strips x seg_rows rows of
+        // the rank's strips (with the rows either side this pass must also produce), about four workgroups per compute unit
+        // (768 ... 2048 measured the same); pass 0: the ring holds the colour plane only -- 34 VGPRs, 9 KB of LDS: eight
+        const int strips = (p.W + 63) / 64;
+        const int strip_ext = p.sh.nranks == 1 ? p.H : per;                 // rows of a local strip with its extension
+        const int total = p.sh.nranks == 1 ? p.H : rows;
+        int wgs = (inf ? 2048 : 1024) / strips; if (wgs < 1) wgs = 1;
+        int seg_rows = ((total + wgs - 1) / wgs + 3) & ~3; if (seg_rows < 8) seg_rows = 8;
+        const int segs = (strip_ext + seg_rows - 1) / seg_rows;
+        dim3 g2((unsigned)strips, (unsigned)(segs * p.sh.n_local_strips));
+        const int U = (4 + 2 * R + 3) / 4;
+        const size_t l2 = (size_t)(64 + 2 * R) * (size_t)(4 * (U + 1)) * (inf ? 4 : 24);
+        if (inf) {
+            if (R == 1) { if (shipped) hipLaunchKernelGGL((k_denoise_ver<true, true, 1, true>), g2, block, l2, s, p, R, seg_rows, segs);
+                          else         hipLaunchKernelGGL((k_denoise_ver<false, true, 1, true>), g2, block, l2, s, p, R, seg_rows, segs); }
+            else        { if (shipped) hipLaunchKernelGGL((k_denoise_ver<true, true, 0, true>), g2, block, l2, s, p, R, seg_rows, segs);
+                          else         hipLaunchKernelGGL((k_denoise_ver<false, true, 0, true>), g2, block, l2, s, p, R, seg_rows, segs); }
+        } else {
             const bool flag = !(p.mode & VRT_DENOISE_FAST);
 #define VRT_LAUNCH_VER(SH_, FL_)                                                                                                  \
             switch (R) {                                                                                                          \
-            case 2:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 2>), g2, block, l2, s, p, R, seg_rows); break;                       \
-            case 3:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 3>), g2, block, l2, s, p, R, seg_rows); break;                       \
-            case 5:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 5>), g2, block, l2, s, p, R, seg_rows); break;                       \
-            default: hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 0>), g2, block, l2, s, p, R, seg_rows); break;                       \
+            case 2:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 2>), g2, block, l2, s, p, R, seg_rows, segs); break;                 \
+            case 3:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 3>), g2, block, l2, s, p, R, seg_rows, segs); break;                 \
+            case 5:  hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 5>), g2, block, l2, s, p, R, seg_rows, segs); break;                 \
+            default: hipLaunchKernelGGL((k_denoise_ver<SH_, FL_, 0>), g2, block, l2, s, p, R, seg_rows, segs); break;                 \
             }
             if (flag) { if (shipped) { VRT_LAUNCH_VER(true, true) } else { VRT_LAUNCH_VER(false, true) } }
             else      { if (shipped) { VRT_LAUNCH_VER(true, false) } else { VRT_LAUNCH_VER(false, false) } }
 #undef VRT_LAUNCH_VER
         }
+    }
+    else if (tiled) {
+        size_t lds = (size_t)(64 + 2 * R) * (size_t)(4 + 2 * R) * (inf ? 16 : 48);   // pass 0 stages the colour plane only
+        if (false) {}
         else if (!inf && (p.mode & VRT_DENOISE_FAST) && p.sh.nranks == 1 && p.extend == 0) {
             const int th = p.tile16 ? 16 : 8;                                // development switch: tile height 8 / 16
             dim3 g2((unsigned)((p.W + 63) / 64), (unsigned)((p.H + th - 1) / th));
