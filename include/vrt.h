@@ -274,7 +274,7 @@ int  vrt_denoise(vrt_ctx* ctx, int32_t W, int32_t H, const vrt_denoiser_settings
                  uint8_t* target0, uint8_t* target1, const vrt_shard* shard, const uint8_t** result);
 /* Sum of the per-pass tap reach ceil(stepWidth_i) over all passes: rows a strip needs from its neighbours. */
 int  vrt_denoise_halo_rows(const vrt_denoiser_settings* ds);
-/* A weighted pass (pass >= 1) of a whole frame with an integral tap offset is computed in two steps: a cheap evaluation of
+/* A pass with an integral tap offset (<= 5; whole frames and sharded passes alike) is computed in two steps: a cheap evaluation of
  * every pixel (hardware exponential and reciprocal, integer code distances) and a second, literal one -- the operations of
  * denoiser.frag:48-72 as the numeric spec fixes them -- of the pixels whose cheap value lies within `guard` RGBA8 codes of a
  * rounding boundary of the RGBA8 target (csrc/vrt_denoise_bound.h derives the guard).  The image is the literal evaluation's,
