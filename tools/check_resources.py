@@ -27,6 +27,10 @@ BUDGET = {
     "k_primaryILi7ELb0ELi2ELb1ELi2EE": ("megakernel, table", 72, 96, 512),
     "k_primaryILi6ELb0ELi2ELb0ELi0EE": ("megakernel over bricks (config 5), one frame per launch", 80, 96, 576),
     "k_denoise_ldsILb0ELb0ELb0ELb1EE": ("K3 weighted pass, exact, packed", 128, 96, 0),
+    # (the verified pass: four workgroups of four waves per compute unit, i.e. at most 128 VGPRs; 96 leaves it five)
+    "k_denoise_verILb0ELb1ELi3ELb0EE": ("K3 verified weighted pass, tap offset 3 (the reference's pass 1)", 96, 96, 0),
+    "k_denoise_verILb0ELb1ELi5ELb0EE": ("K3 verified weighted pass, tap offset 5 (the reference's pass 2)", 96, 96, 0),
+    "k_denoise_verILb0ELb1ELi1ELb1EE": ("K3 verified pass 0", 64, 96, 0),
 }
 
 
