@@ -2050,13 +2050,15 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
         // a weighted mean of codes, + 0.5: its floor is the output, its fraction says how far the nearest rounding boundary is
         const float y0f = __builtin_fmaf(a0, r, 0.5f), y1f = __builtin_fmaf(a1, r, 0.5f), y2f = __builtin_fmaf(a2, r, 0.5f);
         const float f0 = __builtin_amdgcn_fractf(y0f), f1 = __builtin_amdgcn_fractf(y1f), f2 = __builtin_amdgcn_fractf(y2f);
-        const uint32_t o0 = (uint32_t)fminf(y0f - f0, 255.0f), o1 = (uint32_t)fminf(y1f - f1, 255.0f), o2 = (uint32_t)fminf(y2f - f2, 255.0f);
+        // (the truncation is the floor -- the means are positive -- and cannot pass 255: a mean of codes with positive weights is at most
+        // 255 (1 + 20 eps), + 0.5; a NaN converts to 0 and is redone anyway)
+        const uint32_t o0 = (uint32_t)y0f, o1 = (uint32_t)y1f, o2 = (uint32_t)y2f;
         // sure <=> every channel's fraction lies further than the guard from 0 and from 1 (a NaN mean compares false)
         bool sure = !FLAG || (__builtin_fabsf(f0 - 0.5f) < half_guard && __builtin_fabsf(f1 - 0.5f) < half_guard && __builtin_fabsf(f2 - 0.5f) < half_guard);
         uint32_t o3 = 0u;                                        // (W4 = false: the mean of zeros is 0, half a code from either boundary)
         if (W4) {
             const float y3f = __builtin_fmaf(a3, r, 0.5f), f3 = __builtin_amdgcn_fractf(y3f);
-            o3 = (uint32_t)fminf(y3f - f3, 255.0f);
+            o3 = (uint32_t)y3f;
             if (FLAG) sure = sure && __builtin_fabsf(f3 - 0.5f) < half_guard;
         }
         out_codes = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24); out_idx = (uint32_t)py * (uint32_t)P.W + (uint32_t)px; out_sure = sure;
