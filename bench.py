@@ -6,7 +6,7 @@ algorithmic GB/s of the primary-ray DDA kernel against the MI355X HBM peak.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input: a batch of N x F frames (N = number of GPUs,
-F = --frames-per-gpu, default 64 on one GPU and 32 on several; consecutive camera poses of the same 8-unit dolly move at every N and F), every frame cut
+F = --frames-per-gpu, default 128 on one GPU and 32 on several -- a rank's launch then has 128 ... 256 frame slots at every N; consecutive camera poses of the same 8-unit dolly move at every N and F), every frame cut
 into screen strips that are dealt to the N ranks.  A rank traces its strips of ALL frames of the batch with ONE K1 launch
 (vrt_render_geometry_batch / _slots: the next frame's tiles are dispatched while the previous frame drains), packs
 them, and ONE RCCL collective per step moves the strips to where the frames are assembled: frame block b (F frames) is
@@ -77,7 +77,7 @@ def parse_args():
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--traversal", default="AUTO", choices=["AUTO", "DENSE", "BITMASK", "JUMP", "DF", "DFJ"])
     ap.add_argument("--frames-per-gpu", type=int, default=None,
-                    help="frames of the batch per GPU and step; default 64 on one GPU, 32 on several (a rank holds the planes of "
+                    help="frames of the batch per GPU and step; default 128 on one GPU, 32 on several (a rank holds the planes of "
                          "ALL N x F frames of a step: 77 MB each at 1080p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip single_frame_launch and extra_configs (profiling runs)")
@@ -393,7 +393,7 @@ def main():
     st = vrt.VoxelRenderSettings.primary_only((W, H), trav)
     renderer = vrt.VoxelRenderer(engine, st, scene)
     pos0, yaw, pitch = vrt.synthetic.default_camera_for(NV, NV, NV)
-    per_gpu = args.frames_per_gpu if args.frames_per_gpu else (64 if world == 1 else 32)
+    per_gpu = args.frames_per_gpu if args.frames_per_gpu else (128 if world == 1 else 32)
     F = world * max(1, per_gpu)                               # frames of a batch
     # the same dolly move at every N and batch size (8 units of travel per step), sampled as finely as the batch has frames:
     # the rays per frame and their cost do not drift with N
