@@ -22,12 +22,19 @@ collective and no copy.
 Workload = BASELINE.json configs[1]: treehouse stand-in (synthetic:treehouse(seed=2), 256^3 -- the real
 treehouse.vox is a git-LFS pointer in the reference checkout), 1920x1080, primary rays only.
 
-roofline.frac is computed over the work the kernel PERFORMS: 1 B per DDA iteration the product march really takes (summed over
-every frame of the launch, from the march's own counters) + 37 B per pixel, over the kernel's measured duration.  The same
-formula over the iterations of the REFERENCE's loop (SURVEY 8(d)'s count; rays end early at open cells and untagged blocks are
-not traced, so the product takes fewer) is kept as roofline.frac_reference_steps -- it passes 1 and is not a bound.
-roofline.hbm_frac is the PMC traffic (profiles/*_k_primary_pmc.json, quoted only while its csrc digest matches) over the same
-time and peak; roofline.write_floor_ms the stored bytes at the 6.1 TB/s plain stores reach on this part.
+Three byte counts per launch, all over the kernel's measured duration and the 8 TB/s peak (DESIGN.md 7 has the table):
+  roofline.frac            SURVEY 8(d)'s accounting over the work the kernel PERFORMS: 1 B per DDA iteration the product march takes (every
+                           frame of the launch, counted by the counting twins of the loops that are timed) + 37 B per pixel.  An iteration of
+                           a clearance run is an ADDITION IN A REGISTER, not a fetch: this figure measures arithmetic in byte units.
+  roofline.frac_requested  the bytes lanes really ask memory for: one per clearance look-up of a live lane, one per voxel id read, + the
+                           37 B per pixel stored.  This is the memory statement; it agrees with the counters (hbm_frac) to within the
+                           G-buffer's write-combining.
+  roofline.hbm_frac        what the counters saw: FETCH_SIZE / WRITE_SIZE of the same command (profiles/r04_k_primary_pmc.json, quoted only
+                           while its csrc digest matches).
+roofline.frac_reference_steps keeps 8(d)'s formula over the iterations of the REFERENCE's loop (the product proves most of them
+unnecessary and does not take them: the figure passes 1 and is not a bound); roofline.bound_in_practice says what the kernel is
+bound by -- vector-instruction issue -- with the counters behind it; roofline.write_floor_ms is the stored bytes at the 6.1 TB/s
+plain stores reach on this part.
 
 Besides the headline the JSON line carries (rank 0, N = 1, outside the timed region):
   roofline.single_frame_launch   the same kernel with ONE frame per launch (the reference's call pattern, engine.cpp:81-92)
@@ -47,6 +54,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured-achievable
+N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 4    # 256 CUs x 4 SIMDs; a full-width wave64 vector instruction occupies its SIMD for 4 cycles
 STORE_GBS = 6100.0             # what plain stores reach on this part (same guide): the floor of a kernel that only writes its G-buffer
 B_OUT = 37                     # bytes stored per pixel: the reference's 6-target G-buffer (geometry_stage.cpp:22-33)
 K3_BYTES_PASS0 = 8             # denoiser pass 0 (phi = +inf): colour in + colour out
@@ -168,13 +176,16 @@ def median(xs):
     return xs[len(xs) // 2]
 
 
-def marched_counts(vrt, torch, engine, scene, st, push, W, H):
+def marched_counts(vrt, torch, engine, scene, st, push, W, H, lookups=False):
     """(DDA iterations of the primary rays, of all rays, rays traced) as the PRODUCT march performs them for one frame:
     VRT_FLAG_MARCHED_COUNTS makes the count planes report the march's own work -- rays end at open cells, untagged blocks are not
-    traced, an any-hit ray decided at a look-up reports the iterations it took -- where they otherwise hold the REFERENCE loop's."""
+    traced, an any-hit ray decided at a look-up reports the iterations it took -- where they otherwise hold the REFERENCE loop's.
+    The launch runs the counting twins of the very loops the timed launch runs (threshold runs included: vrt_traverse.h CNT).
+    lookups=True (VRT_FLAG_LOOKUP_COUNTS): the BYTES the march asks for instead -- one per clearance look-up of a live lane, one per
+    voxel id read: an iteration of a clearance run is an addition in a register, not a fetch."""
     import ctypes as C
     gbm = vrt.GeometryBuffer(engine, W, H, ("steps_primary", "steps_total", "rays_total"))
-    stc = st.to_c(); stc.flags |= 16
+    stc = st.to_c(); stc.flags |= 16 | (32 if lookups else 0)
     frm = gbm.to_c()
     vrt._capi.check(vrt.lib().vrt_render_geometry(engine.ctx, scene.handle, C.byref(push), C.byref(stc), C.byref(frm), None))
     engine.synchronize()
@@ -207,8 +218,29 @@ def single_frame_launch(vrt, engine, renderer, pushes, W, H, S_frames, M_frames=
             "sample": f"{len(pushes)} poses of the step, one vrt_render_geometry call each, device idle between launches"}
 
 
+def pmc_figures(tag, kernel_ms):
+    """HBM traffic and the vector unit's share of one launch from the committed PMC summary of this workload (profiles/r04_<tag>_pmc.json;
+    quoted only while the kernel sources are the ones it was collected on)."""
+    path = os.path.join(ROOT, "profiles", f"r04_{tag}_pmc.json")
+    try:
+        pj = json.load(open(path))
+        if pj.get("csrc_sha16") != csrc_sha16():
+            return {"pmc_source": f"dropped: {os.path.basename(path)} was collected on other kernel sources"}
+        c = pj["counters"]
+        hb = pj["hbm_bytes_per_launch"]
+        out = {"pmc_source": os.path.relpath(path, ROOT), "hbm_bytes": int(hb["total_guide_rule"]), "hbm_bytes_raw_fetch": int(hb["total_raw_fetch"]),
+               "hbm_frac": round(hb["total_guide_rule"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        if "SQ_INSTS_VALU" in c:
+            out["valu_insts"] = int(c["SQ_INSTS_VALU"]["mean_per_launch"])
+            out["valu_issue_ms"] = round(c["SQ_INSTS_VALU"]["mean_per_launch"] * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3, 5)
+            out["valu_issue_frac"] = round(out["valu_issue_ms"] / kernel_ms, 4)
+        return out
+    except Exception as e:
+        return {"pmc_source": f"none: {e}"}
+
+
 def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounces, iters, reps=9, max_steps=512, kernel="k_primary<DF, megakernel>",
-                 batch_pushes=None):
+                 batch_pushes=None, pmc=None):
     """One frame of a secondary-ray configuration: kernel times from the library's HIP events (median of `reps` isolated
     frames), ray / step counts from a second render with the count planes attached."""
     st = vrt.VoxelRenderSettings(targetResolution=(W, H))
@@ -238,14 +270,19 @@ def extra_config(vrt, torch, engine, scene, push, W, H, name, ao, shadows, bounc
     engine.set_timing(False)
     g_ms = median(tg)
     _, S_marched, _ = marched_counts(vrt, torch, engine, scene, st, push, W, H)
+    _, Q_req, _ = marched_counts(vrt, torch, engine, scene, st, push, W, H, lookups=True)
     b_ref = S + W * H * B_OUT                                  # the reference loop's iterations (SURVEY 8(d)'s count)
     b_geo = S_marched + W * H * B_OUT                          # the iterations the product march takes
+    b_req = Q_req + W * H * B_OUT                              # the bytes its lanes ask for + the G-buffer
     out = {"name": name, "ao_samples": ao, "shadows": int(bool(shadows)), "max_bounces": bounces, "denoiser_passes": iters,
            "resolution": [W, H], "max_steps": max_steps, "geometry_kernel": kernel, "geometry_ms": round(g_ms, 5),
            "rays_total": rays, "dda_steps_total": S, "dda_steps_marched": S_marched, "Mrays_total_per_s": round(rays / (g_ms * 1e-3) / 1e6, 1),
            "geometry_algorithmic_bytes": b_geo, "geometry_frac": round(b_geo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
            "geometry_frac_reference_steps": round(b_ref / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+           "requested_bytes": b_req, "geometry_frac_requested": round(b_req / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
            "write_floor_ms": round(W * H * B_OUT / (STORE_GBS * 1e9) * 1e3, 5)}
+    if pmc:
+        out.update(pmc_figures(pmc, g_ms))
     if batch_pushes:
         # the same settings with several frames per launch (consecutive poses): a hit wave's chain of secondary traces then has
         # other frames' waves to hide behind, as the headline's primary rays have
@@ -472,7 +509,7 @@ def main():
         engine.set_timing(True)
         st_dbg = vrt.VoxelRenderSettings.primary_only((W, H), vrt.TRAVERSAL_BITMASK)
         stage = vrt.GeometryStage(engine, st_dbg, scene, debug_planes=True)
-        S_frames, M_frames, hit_frac = [], [], []
+        S_frames, M_frames, Q_frames, hit_frac = [], [], [], []
         frames_per_launch = min(F, 256)
         for f in range(frames_per_launch):                    # the frames of the first launch of a step
             gb = stage.record(pushes[f])
@@ -480,6 +517,7 @@ def main():
             S_frames.append(int(gb.steps_primary.to(torch.int64).sum().item()))
             hit_frac.append(float((gb.hit_id != 0).float().mean().item()))
             M_frames.append(marched_counts(vrt, torch, engine, scene, st, pushes[f], W, H)[0])
+            Q_frames.append(marched_counts(vrt, torch, engine, scene, st, pushes[f], W, H, lookups=True)[0])
         del stage, gb
         scene.trim()                                           # the count planes' second set of clearance fields: not carried through the legs below
         S_frame = S_frames[0]
@@ -497,13 +535,14 @@ def main():
         px_bytes = frames_per_launch * W * H * B_OUT / world
         b_alg = sum(M_frames) / world + px_bytes
         b_ref = sum(S_frames) / world + px_bytes
+        b_req = sum(Q_frames) / world + px_bytes
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         tm = engine.last_timings()
         # HBM bytes per K1 launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
         # this same command; tools/pmc_summary.py -> profiles/*_k_primary_pmc.json).  Counters cannot be read from inside
         # the process, so the committed summary is quoted -- only for the configuration AND the kernel sources it was
         # collected on (the summary carries the digest of csrc/; another digest means the number is stale and is dropped).
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k_primary_pmc.json")))
         if pm and world == 1 and (W, H, NV) == (1920, 1080, 256) and args.traversal in ("AUTO", "DF"):
@@ -516,12 +555,22 @@ def main():
                                      f"({pj.get('csrc_sha16')} != {csrc_sha16()})")
                 traffic = int(pj["hbm_bytes_per_launch"]["total_guide_rule"])
                 traffic_src = os.path.relpath(pm[-1], ROOT)
+                valu = pj["counters"].get("SQ_INSTS_VALU", {}).get("mean_per_launch")
             except Exception as e:
                 traffic, traffic_src = None, f"dropped: {e}"
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "frac_is": "bytes of the work PERFORMED (1 B per DDA iteration the product march takes, summed over the launch's frames, "
-                               "+ 37 B per pixel) / kernel time / peak",
+                    "frac_is": "SURVEY 8(d)'s accounting over the work PERFORMED: 1 B per DDA iteration the product march takes (every frame of the launch, counted "
+                               "by the twins of the loops that are timed) + 37 B per pixel, / kernel time / peak.  An iteration of a clearance run is an addition in a "
+                               "register, not a fetch: this measures arithmetic in byte units; frac_requested is the memory statement",
+                    "requested_bytes_per_launch": int(b_req), "lane_lookups_per_launch": int(sum(Q_frames)),
+                    "frac_requested": round(b_req / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "frac_requested_is": "bytes the lanes ASK memory for (one per clearance look-up of a live lane, one per voxel id read) + 37 B per pixel stored, "
+                                         "/ kernel time / peak",
+                    "bound_in_practice": ({"what": "vector-instruction issue", "valu_insts_per_launch": int(valu),
+                                           "valu_issue_ms": round(valu * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3, 5),
+                                           "valu_issue_frac_of_kernel": round(valu * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3 / kern_ms, 4),
+                                           "model": f"SQ_INSTS_VALU x {VALU_CYCLES} cycles / {N_SIMD} SIMDs / {CLOCK_HZ / 1e9} GHz (same PMC file)"} if valu else None),
                     "hbm_frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                     "traffic_GBps": round(traffic / (kern_ms * 1e-3) / 1e9, 2) if traffic else None,
                     "write_floor_ms": round(px_bytes / (STORE_GBS * 1e9) * 1e3, 5),
@@ -540,6 +589,8 @@ def main():
                 ("configs[2]: primary + shadow ray, 1 denoiser pass", 0, True, 0, 1),
                 ("configs[2]: primary + shadow ray, 2 denoiser passes", 0, True, 0, 2),
                 ("reference defaults: AO 4 x 64 steps, shadow ray, <= 5 bounces, 2 denoiser passes", 4, True, 5, 2))]
+            for e, tag in zip(extra, ("config3", "config3", "defaults")):
+                e.update(pmc_figures(tag, e["geometry_ms"]))
             # the same three workloads one frame per call with 1, 2 and 3 frames in flight (the reference's own pattern)
             st_c3 = vrt.VoxelRenderSettings.primary_only((W, H)); st_c3.traceSettings.shadows = True
             st_df = vrt.VoxelRenderSettings(targetResolution=(W, H)); st_df.fsrSetttings.enable = False
@@ -559,7 +610,7 @@ def main():
                                     (512, 512, 512), (3840, 2160), frame=5 + k) for k in range(4)]
             em = extra_config(vrt, torch, engine, scm, pushm, 3840, 2160,
                               "configs[3]: synthetic:mandelbulb(N=512), 3840x2160, 2 bounces, AO 4 x 64 steps, shadow ray", 4, True, 2, 0,
-                              reps=5, kernel="k_primary<DF, megakernel>", batch_pushes=batchm)
+                              reps=5, kernel="k_primary<DF, megakernel>", batch_pushes=batchm, pmc="mandelbulb")
             em["scene_device_bytes"] = scm.memory_bytes()
             em["scene_build_s"] = round(time.perf_counter() - t_gen, 2)
             extra.append(em)
@@ -575,7 +626,7 @@ def main():
             push5 = vrt.make_push(cam5, (2048, 2048, 2048), (3840, 2160), frame=17)
             e5 = extra_config(vrt, torch, engine, sc5, push5, 3840, 2160,
                               "configs[4]: synthetic:sparse2048(seed=5) brick scene (1.5 % of 8^3 bricks), 3840x2160, max_steps 6144, 4 bounces, AO 4", 4, True, 4, 0,
-                              reps=5, max_steps=6144, kernel="k_primary<BRICK, megakernel>")
+                              reps=5, max_steps=6144, kernel="k_primary<BRICK, megakernel>", pmc="brick")
             e5["scene_device_bytes"] = sc5.memory_bytes()
             e5["scene_bricks"] = int(pool.shape[0])
             e5["scene_build_s"] = round(time.perf_counter() - t_gen, 2)
@@ -586,7 +637,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is reported at N = 1 only
             from oracle import oracle                          # checker / CPU baseline only
             osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
-            ncores = min(os.cpu_count() or 1, 16)
+            # every hardware thread this process may run on; the counts are in the line.  (A GPU box of the pool gives a
+            # one-GPU job a share of the host -- os.sched_getaffinity -- not all of os.cpu_count(); above 128 threads the oracle gains nothing.)
+            try:
+                usable = len(os.sched_getaffinity(0))
+            except Exception:
+                usable = os.cpu_count() or 1
+            ncores = max(1, min(usable, 128))
             # a bounded sample of the same workload: every (F / 8)-th frame of the step, i.e. 8 full frames spread over the
             # camera path (about 10 CPU-seconds at 1080p: 0.6 s of wall time on 16 threads)
             sample = list(range(0, F, max(1, F // 8)))[:8]
@@ -598,7 +655,7 @@ def main():
                     same = bool((exp["hit_id"] == hit0).all()) and int(exp["steps_primary"].sum()) == S_frame
                     same_color = bool((exp["color8"] == color0).all())
             cdt = time.perf_counter() - c0
-            cpu = {"value": round(len(sample) * W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "kind": "port",
+            cpu = {"value": round(len(sample) * W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "hardware_threads": os.cpu_count(), "usable_threads": usable, "kind": "port",
                    "sample": f"{len(sample)} full {W}x{H} frames of the same workload (every {max(1, F // 8)}th pose of the step), scalar C oracle, "
                              f"rows interleaved over {ncores} threads, {cdt:.2f} s",
                    "hit_ids_match_gpu": same, "color8_matches_gpu": same_color,

@@ -75,7 +75,12 @@ typedef struct vrt_push {
 #define VRT_FLAG_MARCHED_COUNTS 16u /* the count planes (steps_primary, steps_total, rays_total) report the PRODUCT march's own work -- rays
                                      * end at open cells, untagged blocks are not traced, an any-hit ray decided at a look-up reports the
                                      * iterations it took -- instead of the reference loop's iterations; every other plane is unchanged.
-                                     * bench.py's roofline figures count these */
+                                     * bench.py's roofline figures count these.  The launch runs the counting twins of the look-up loops: the same
+                                     * march as the product launch (threshold runs included: a threshold run reports the steps its axes took,
+                                     * which is the iteration count unless two axes tie) */
+#define VRT_FLAG_LOOKUP_COUNTS 32u  /* with VRT_FLAG_MARCHED_COUNTS: the count planes hold the BYTES the march asked for instead of its iterations --
+                                     * one per clearance look-up of a live lane (three where the look-ups prefetch), one per voxel id read; brick
+                                     * scenes: 8 per brick word, 1 per fine byte and id.  What bench.py reports as roofline.requested_bytes */
 
 /* VolumeParameters (parameters.hpp:5-9) + Light (voxel_scene.hpp:10-15) as GeometryStage::record fills
  * them each frame (geometry_stage.cpp:135-145), plus the shader's compile-time constants
@@ -142,14 +147,17 @@ void vrt_ctx_destroy(vrt_ctx* ctx);                         /* Engine::destroy *
  * torch's default stream is. */
 int  vrt_ctx_set_stream(vrt_ctx* ctx, void* hip_stream);
 int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle(), engine.cpp:351 */
-/* Development switches of a context (no reference analogue; the reference's counterpart is recompiling a shader): every
- * one is 1 by default and changes speed only, never a result -- the tests render "the same frame without X" with them.
- * Names: "tile_tags", "box_rect", "xcd_regions", "fast_loop", "thresh_runs", "hit_table", "no_bounce_kernel", "sky_fast" (looked at by every
- * vrt_render_geometry* call), "denoise_th16", "denoise_packed", "denoise_verified" (by vrt_denoise; "denoise_guard_div8" and
- * "denoise_count", both 0 by default, are the tests' handles on the verified pass) and "open_cells", "df_prefetch", "df_own"
- * (looked at when a scene is created).  The
- * environment seeds them ONCE, at vrt_ctx_create (VRT_TILE_TAGS=0, VRT_SKY_FAST=0, ...); nothing on the render path
- * calls getenv.  Unknown name: VRT_ERR_INVALID. */
+/* Development switches of a context (no reference analogue; the reference's counterpart is recompiling a shader): each changes
+ * speed only, never a result -- the tests render "the same frame without X" with them.  Name (default), who looks at it:
+ *   every vrt_render_geometry* call:  "tile_tags" (1), "box_rect" (1), "fast_loop" (1), "thresh_runs" (1), "ao_thresh" (1), "hit_table" (1),
+ *                                     "no_bounce_kernel" (1), "packed_bounces" (1), "sky_fast" (1),
+ *                                     "xcd_regions" (0 -- until round 3 VRT_XCD_REGIONS was on by default; as a three-dimensional grid the
+ *                                     form ran 30.0 or 33.6 us per bench frame from one process to the next, so it is opt-in now)
+ *   vrt_denoise:                      "denoise_packed" (1), "denoise_verified" (1), "denoise_th16" (0: the tolerance kernel's 64 x 16 tiles
+ *                                     are an experiment), and the tests' handles on the verified pass "denoise_guard_div8" (0), "denoise_count" (0)
+ *   scene creation:                   "open_cells" (1), "df_prefetch" (1), "df_own" (1)
+ * The environment seeds them ONCE, at vrt_ctx_create (VRT_TILE_TAGS=0, VRT_SKY_FAST=0, ...); nothing on the render path calls
+ * getenv.  Unknown name: VRT_ERR_INVALID. */
 int  vrt_ctx_set_option(vrt_ctx* ctx, const char* name, int32_t value);
 int  vrt_ctx_get_option(vrt_ctx* ctx, const char* name, int32_t* value);
 const char* vrt_last_error(void);
@@ -223,7 +231,11 @@ void vrt_settings_default(vrt_settings* s);
 /* ---- geometry stage -------------------------------------------------------------------------- */
 /* GeometryStage::record (geometry_stage.cpp:106-153) == one full-screen run of voxel_volume.frag:
  * primary-ray DDA kernel + (when AO / shadow / reflection rays are enabled) the secondary-ray and
- * shading kernels.  Asynchronous on the context stream. */
+ * shading kernels.  Asynchronous on the context stream.
+ * Limits: screen_size up to 32768 per side and below 2^28 pixels per frame (16384 x 16384 is refused with
+ * VRT_ERR_UNSUPPORTED): a launch addresses the full-frame planes with 32-bit byte offsets -- 16 B per pixel in the
+ * position plane -- and sharded launches (vrt_shard) index the same full-frame planes, so strips do not lift the limit;
+ * a larger image is rendered as several frames whose camera planes are shifted. */
 int  vrt_render_geometry(vrt_ctx* ctx, const vrt_scene* sc, const vrt_push* push,
                          const vrt_settings* settings, const vrt_frame* frame, const vrt_shard* shard);
 

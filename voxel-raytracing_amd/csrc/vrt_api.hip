@@ -38,8 +38,8 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 } // namespace
 
-// Development switches of a context: A/B experiments and the tests' "the same frame without X" runs.  Every one defaults to on
-// and changes speed only, never a result.  Seeded ONCE, at vrt_ctx_create, from the environment (VRT_TILE_TAGS=0 ...); nothing
+// Development switches of a context: A/B experiments and the tests' "the same frame without X" runs.  Each changes speed only,
+// never a result; the defaults are the initialisers below (include/vrt.h lists them: not every one is on).  Seeded ONCE, at vrt_ctx_create, from the environment (VRT_TILE_TAGS=0 ...); nothing
 // on the render path reads the environment.  vrt_ctx_set_option changes them per context.
 struct DevOptions {
     int tile_tags = 1;         // k_tile_tags ahead of K1
@@ -48,6 +48,8 @@ struct DevOptions {
                                // grid the form runs 30 or 33.6 us per bench frame from one process to the next; rows dealt to the XCDs: 30.0)
     int fast_loop = 1;         // AUTO / DF through the hand-written look-up loop
     int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
+    int packed_bounces = 1;    // the megakernel's bounce chain as one word per hit (no stack of hits in scratch)
+    int ao_thresh = 1;         // AO rays through the threshold loop (df_ao_loop), the counting loop only where the step bound straddles the budget
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
     int thresh_runs = 1;       // primary rays through df_prim_loop (long runs by threshold)
     int hit_table = 1;         // launches without secondary rays take a hit's colour from the table of colorHit() over materials x normals
@@ -65,6 +67,7 @@ static const OptName kOptNames[] = {
     {"tile_tags", "VRT_TILE_TAGS", &DevOptions::tile_tags}, {"box_rect", "VRT_BOX_RECT", &DevOptions::box_rect},
     {"xcd_regions", "VRT_XCD_REGIONS", &DevOptions::xcd_regions}, {"fast_loop", "VRT_FAST_LOOP", &DevOptions::fast_loop},
     {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
+    {"packed_bounces", "VRT_PACKED_BOUNCES", &DevOptions::packed_bounces}, {"ao_thresh", "VRT_AO_THRESH", &DevOptions::ao_thresh},
     {"hit_table", "VRT_HIT_TABLE", &DevOptions::hit_table},
     {"thresh_runs", "VRT_THRESH_RUNS", &DevOptions::thresh_runs}, {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
     {"denoise_verified", "VRT_DENOISE_VERIFIED", &DevOptions::denoise_verified}, {"denoise_guard_div8", "VRT_DENOISE_GUARD_DIV8", &DevOptions::denoise_guard_div8},
@@ -638,7 +641,9 @@ int vrt_scene_trim(vrt_ctx* c, vrt_scene* s)
 {
     if (!c || !s) return fail(VRT_ERR_INVALID, "vrt_scene_trim: NULL argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // a scene may be shared by several contexts (frames in flight: one stream each); a count-plane launch enqueued on ANY of them
+    // may still be reading the fields freed below, so this waits for the whole device, not for the calling context's stream
+    HIPCHK(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lock(s->lazy);
     if (s->df_counts) {
         hipFree(s->df_counts - s->df_guard);
@@ -888,7 +893,8 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     int W = push->screen_size[0], H = push->screen_size[1];
     if (W <= 0 || H <= 0 || W > 32768 || H > 32768) return fail(VRT_ERR_INVALID, "vrt_render_geometry: bad screen_size");
     if ((uint64_t)W * (uint64_t)H >= (1ull << 28))              // K1 addresses a plane with 32-bit byte offsets (16 B per pixel at most)
-        return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: frames of 2^28 pixels and more are not supported (render in strips: vrt_shard)");
+        return fail(VRT_ERR_UNSUPPORTED, "vrt_render_geometry: frames of 2^28 pixels and more are not supported (a launch indexes full-frame planes with "
+                                         "32-bit byte offsets, sharded or not: render such an image as several frames with shifted camera planes; include/vrt.h)");
     for (int f = 0; f < n; f++) {
         const vrt_push& q = pushes[f];
         if (q.screen_size[0] != W || q.screen_size[1] != H)
@@ -924,6 +930,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     // open cells (with the development flags the planes hold the product march's own counters instead)
     bool counts = false;
     p.sc.vol.count_marched = (st->flags & VRT_FLAG_MARCHED_COUNTS) ? 1u : 0u;
+    p.sc.vol.count_lookups = ((st->flags & VRT_FLAG_MARCHED_COUNTS) && (st->flags & VRT_FLAG_LOOKUP_COUNTS)) ? 1u : 0u;
     if (!(st->flags & (VRT_FLAG_DEBUG_PLANES | VRT_FLAG_MARCHED_COUNTS | 2u)))
         for (int f = 0; f < n && !counts; f++) counts = frames[f].steps_primary != nullptr || frames[f].steps_total != nullptr;
     if (s->bricks && counts) p.sc.vol.brick_open = 0u;
@@ -999,6 +1006,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && (st->max_bounces == 0 || !s->metallic_voxels)) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
     p.no_bounce = ((st->max_bounces == 0 || !s->metallic_voxels) && c->opt.no_bounce_kernel) ? 1 : 0;
+    p.packed_chain = (c->opt.packed_bounces && st->ao_samples <= 0xFFFFu) ? 1 : 0;     // (16 bits of a chain word count the AO rays that hit)
     // default traversal and budgets the recovery of positions from sideDist is exact for: the hand-written look-up loop
     // (vrt_traverse.h trace_df_fast) for every ray of the frame
     {
@@ -1008,11 +1016,11 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         bool ok = want && df && s->d.vol.df_fast && st->max_steps >= 1 && st->max_steps <= 1024 && p.tile_h == 8 &&
                   !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (!sec || st->ao_samples == 0 || (st->ao_steps >= 1 && st->ao_steps <= 1024));
         for (int f = 0; f < n && ok; f++) ok = frames[f].hit_voxel == nullptr;      // the fast loop keeps no mapPos: no hit_voxel plane
-        p.fast_loop = ok ? 1 : 0;
+        p.fast_loop = ok ? ((st->flags & VRT_FLAG_MARCHED_COUNTS) ? 2 : 1) : 0;      // (2: the loops' counting twins)
         // ... and the primary rays' long runs by threshold (df_prim_loop): launches that report no iteration counts (the loop keeps
         // none), axis step counts the position recovery is exact for, a budget worth not counting
         const int dmax = s->d.vol.W > s->d.vol.H ? (s->d.vol.W > s->d.vol.D ? s->d.vol.W : s->d.vol.D) : (s->d.vol.H > s->d.vol.D ? s->d.vol.H : s->d.vol.D);
-        p.sc.vol.df_thresh = (ok && c->opt.thresh_runs && !counts && !(st->flags & VRT_FLAG_MARCHED_COUNTS) && dmax <= 1022 && st->max_steps >= 32) ? 1u : 0u;
+        p.sc.vol.df_thresh = (ok && c->opt.thresh_runs && !counts && dmax <= 1022 && st->max_steps >= 32) ? 1u : 0u;
         // (brick scenes: the generic loop's form of the same, brick_march_thresh; its positions come from per-run differences)
         if (s->bricks) p.sc.vol.df_thresh = (c->opt.thresh_runs && !counts && !(st->flags & (VRT_FLAG_MARCHED_COUNTS | VRT_FLAG_DEBUG_PLANES | 2u)) && st->max_steps >= 32) ? 1u : 0u;
     }

@@ -577,32 +577,76 @@ __device__ __forceinline__ f3 primary_normalize(const f3 v)
     return o;
 }
 
-// calcAmbient + isShadowed + color + colorHit, voxel_volume.frag:205-264
+// calcAmbient + isShadowed + color + colorHit, voxel_volume.frag:205-264, in two halves: the secondary rays of a hit (what they
+// find: how many AO rays hit something, whether the light is hidden) and the arithmetic on what they found.  color_hit is the two
+// one after the other; the packed bounce chain (color_main_ray_packed) runs the first half on the way out and the second on the
+// way back.
 // SEC = false: the host has established ao_samples == 0 and shadows == 0 (K1 MODE 1), so neither loop is compiled in.
 template <int TRAV, class Occ, bool SEC = true>
-__device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit,
-                        f3 reflection, uint32_t depth)
+__device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ occ, PixCtx& c, const f3 pos, const f3 normal, uint32_t depth,
+                                               float& ambient, uint32_t& ao_hits, bool& shadowed)
 {
     const DevScene& s = P.sc;
     const vrt_settings& st = P.st;
-    if (hit.material == 0) return sky_color(s, hit.dir);
-
-    float ambient = 0.0f;
+    ambient = 0.0f; ao_hits = 0u;
     if (!SEC || st.ao_samples == 0) {
         ambient = 1.0f;
     } else {
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
             f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
-            f3 dir = mk3(hit.normal.x + rd.x, hit.normal.y + rd.y, hit.normal.z + rd.z);
-            f3 o = mk3(hit.pos.x + dir.x * 0.01f, hit.pos.y + dir.y * 0.01f, hit.pos.z + dir.z * 0.01f);
+            f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
+            f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
             RayInt r;
             // AO rays have a 64-iteration budget: too short for jumps to pay, and budget ties would force re-traces
             trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV), decltype(occ.o2), false, true, false, true>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);   // (no prefetch: AO rays point every way, three gathers instead of one measured +18 %)
             c.fetches += r.fetches; c.rays++;
-            if (r.material != 0) ambient += sample_frac;
+            if (r.material != 0) { ambient += sample_frac; ao_hits++; }
         }
     }
+    shadowed = false;
+    if (SEC && st.shadows) {
+        f3 L = mk3(st.light_dir[0], st.light_dir[1], st.light_dir[2]);
+        f3 o = mk3(pos.x + normal.x * 0.01f, pos.y + normal.y * 0.01f, pos.z + normal.z * 0.01f);
+        RayInt r;
+        trace_int<TRAV, decltype(occ.o2), false, true, true>(s.vol, occ.o2, occ.o3, o, L, st.max_steps, r);      // traceRayHit: only "did it hit" is used
+        c.fetches += r.fetches; c.rays++;
+        shadowed = r.material != 0;
+    }
+}
+
+// color() of a hit (frag:236-248) and colorHit's division by depth + 1 (frag:258).  `sky` = skyColor(normal).
+__device__ __forceinline__ f3 shade_eval(const GeomParams& P, uint32_t material, const f3 normal, const f3 sky, float ambient, bool shadowed,
+                                         f3 reflection, uint32_t depth)
+{
+    const vrt_settings& st = P.st;
+    float k = ambient * st.ambient_intensity;
+    f3 amb = mk3(k * sky.x, k * sky.y, k * sky.z);
+    f3 L = mk3(st.light_dir[0], st.light_dir[1], st.light_dir[2]);
+    f3 diffuse = mk3(0.0f, 0.0f, 0.0f);
+    if (!shadowed) {
+        float diff = fmaxf(dot3(normal, L), 0.0f);
+        diffuse = mk3((diff * st.light_color[0]) * st.light_intensity,
+                      (diff * st.light_color[1]) * st.light_intensity,
+                      (diff * st.light_color[2]) * st.light_intensity);
+    }
+    const vrt_material mat = P.sc.palette[material];
+    float inv = (float)(depth + 1);
+    f3 out;
+    out.x = ((((diffuse.x + reflection.x * mat.metallic) + amb.x) * mat.diffuse[0]) * 1.0f) / inv;
+    out.y = ((((diffuse.y + reflection.y * mat.metallic) + amb.y) * mat.diffuse[1]) * 1.0f) / inv;
+    out.z = ((((diffuse.z + reflection.z * mat.metallic) + amb.z) * mat.diffuse[2]) * 1.0f) / inv;
+    return out;
+}
+
+template <int TRAV, class Occ, bool SEC = true>
+__device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit,
+                        f3 reflection, uint32_t depth)
+{
+    const DevScene& s = P.sc;
+    if (hit.material == 0) return sky_color(s, hit.dir);
+    float ambient; uint32_t ao_hits; bool shadowed;
+    secondary_rays<TRAV, Occ, SEC>(P, occ, c, hit.pos, hit.normal, depth, ambient, ao_hits, shadowed);
     // skyColor(hit.normal): the normal is one of 26 vectors, whose sky texels the scene holds in a table (computed by this very
     // function, k_sky_normals); any other normal is looked up here
     f3 sky;
@@ -614,32 +658,7 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
         const float4 t = reinterpret_cast<const float4*>(s.sky_normals)[hit.ncode];
         sky = mk3(t.x, t.y, t.z);
     } else sky = sky_color(s, hit.normal);
-    float k = ambient * st.ambient_intensity;
-    f3 amb = mk3(k * sky.x, k * sky.y, k * sky.z);
-
-    bool shadowed = false;
-    f3 L = mk3(st.light_dir[0], st.light_dir[1], st.light_dir[2]);
-    if (SEC && st.shadows) {
-        f3 o = mk3(hit.pos.x + hit.normal.x * 0.01f, hit.pos.y + hit.normal.y * 0.01f, hit.pos.z + hit.normal.z * 0.01f);
-        RayInt r;
-        trace_int<TRAV, decltype(occ.o2), false, true, true>(s.vol, occ.o2, occ.o3, o, L, st.max_steps, r);      // traceRayHit: only "did it hit" is used
-        c.fetches += r.fetches; c.rays++;
-        shadowed = r.material != 0;
-    }
-    f3 diffuse = mk3(0.0f, 0.0f, 0.0f);
-    if (!shadowed) {
-        float diff = fmaxf(dot3(hit.normal, L), 0.0f);
-        diffuse = mk3((diff * st.light_color[0]) * st.light_intensity,
-                      (diff * st.light_color[1]) * st.light_intensity,
-                      (diff * st.light_color[2]) * st.light_intensity);
-    }
-    const vrt_material mat = s.palette[hit.material];
-    float inv = (float)(depth + 1);
-    f3 out;
-    out.x = ((((diffuse.x + reflection.x * mat.metallic) + amb.x) * mat.diffuse[0]) * 1.0f) / inv;
-    out.y = ((((diffuse.y + reflection.y * mat.metallic) + amb.y) * mat.diffuse[1]) * 1.0f) / inv;
-    out.z = ((((diffuse.z + reflection.z * mat.metallic) + amb.z) * mat.diffuse[2]) * 1.0f) / inv;
-    return out;
+    return shade_eval(P, hit.material, hit.normal, sky, ambient, shadowed, reflection, depth);
 }
 
 // colorMainRay, voxel_volume.frag:267-307
@@ -674,6 +693,97 @@ __device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, cons
         }
     }
     return color_hit<TRAV>(P, occ, c, hit, reflection, 0);
+}
+
+// colorMainRay with the bounce chain as ONE WORD per hit instead of a stack of RayHits (44 B each: 352 B of scratch per lane for
+// every wave of the launch, and 0.6 GB of scratch writes per 4K frame on the Mandelbulb).  What the way back needs of a hit on the
+// chain is what color() consumes: its material, which of the 27 normals it has (26 face / edge / corner vectors or the zero
+// vector of rule A: every normal traceRay can produce, hit_normal), how many of its AO rays hit and whether its shadow ray did --
+// 8 + 6 + 16 + 1 bits.  So the secondary rays of every hit are traced on the way OUT, where the hit is at hand, at one call
+// site for the primary hit and every bounce; the way back is arithmetic on the words, in the order frag:300-303 prescribes.
+// The secondary rays of a METALLIC bounce are traced before it is known whether the chain will end (frag:281-298: a chain of
+// max_bounces metallic hits shades none of them, lastIdx = -1): in that one case they were traced for nothing, and their rays
+// and steps are taken out of the count planes again, which then hold the reference's numbers as before.
+// Entry k of the chain: k = 0 the primary hit, k = i + 1 bounce i (shaded with depth i; the primary with depth 0).
+__device__ __forceinline__ uint32_t chain_pack(uint32_t material, const f3 n, uint32_t ao_hits, bool shadowed)
+{
+    // the normal's code from the vector itself: bit a = component a is not 0, bit 3 + a = it is positive (hit_normal's ncode: the
+    // component is -rayStep); a masked axis the ray does not move along has a zero component and drops out of the mask, which is
+    // the same vector hit_normal's general form returns
+    const uint32_t nc = (uint32_t)(n.x != 0.0f) | ((uint32_t)(n.y != 0.0f) << 1) | ((uint32_t)(n.z != 0.0f) << 2) |
+                        ((uint32_t)(n.x > 0.0f) << 3) | ((uint32_t)(n.y > 0.0f) << 4) | ((uint32_t)(n.z > 0.0f) << 5);
+    return material | (nc << 8) | ((uint32_t)shadowed << 14) | (ao_hits << 16);
+}
+__device__ __forceinline__ f3 chain_shade(const GeomParams& P, uint32_t code, f3 reflection, uint32_t depth)
+{
+    const DevScene& s = P.sc;
+    const uint32_t nc = (code >> 8) & 63u, hits = code >> 16;
+    const f3 normal = hit_normal(nc & 7u, (nc & 8u) ? -1 : 1, (nc & 16u) ? -1 : 1, (nc & 32u) ? -1 : 1);
+    f3 sky;
+    if ((nc & 7u) != 0u) { const float4 t = reinterpret_cast<const float4*>(s.sky_normals)[nc]; sky = mk3(t.x, t.y, t.z); }
+    else sky = sky_color(s, normal);                         // the zero normal of rule A
+    // calcAmbient's sum: `hits` additions of 1 / ao_samples (frag:219-222), not a product
+    float ambient = 1.0f;
+    if (P.st.ao_samples != 0u) {
+        const float sample_frac = 1.0f / (float)P.st.ao_samples;
+        ambient = 0.0f;
+        for (uint32_t q = 0; q < hits; q++) ambient += sample_frac;
+    }
+    return shade_eval(P, code & 0xFFu, normal, sky, ambient, ((code >> 14) & 1u) != 0u, reflection, depth);
+}
+
+// NBT: the most bounces the launch can ask for (the chain's words are registers: 2, 5 or VRT_MAX_BOUNCES + 1 of them)
+template <int TRAV, class Occ, int NBT>
+__device__ f3 color_main_ray_packed(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit)
+{
+    const DevScene& s = P.sc;
+    const vrt_settings& st = P.st;
+    const int nb = st.max_bounces > NBT ? NBT : (int)st.max_bounces;
+    uint32_t codes[NBT + 1];
+#pragma unroll
+    for (int q = 0; q <= NBT; q++) codes[q] = 0u;
+    f3 reflection = mk3(0.0f, 0.0f, 0.0f);
+    RayHit cur = hit;
+    int last = 0;                                              // the chain's last entry that is shaded: 0 = the primary hit alone
+    uint32_t spec_fetches = 0u, spec_rays = 0u;
+    for (int k = 0;; k++) {
+        // the secondary rays of entry k (a hit: the primary, or a bounce that found something)
+        float ambient; uint32_t ao_hits; bool shadowed;
+        const uint32_t f0 = c.fetches, r0 = c.rays;
+        secondary_rays<TRAV, Occ, true>(P, occ, c, cur.pos, cur.normal, k > 0 ? (uint32_t)(k - 1) : 0u, ambient, ao_hits, shadowed);
+        codes[k] = chain_pack(cur.material, cur.normal, ao_hits, shadowed);
+        last = k;
+        const bool metal = s.palette[cur.material].metallic > 0.0f;
+        if (!metal) break;                                     // (k = 0: no chain at all; k > 0: the chain ends on a hit that does not reflect)
+        if (k > 0) { spec_fetches += c.fetches - f0; spec_rays += c.rays - r0; }    // a metallic bounce: shaded only if the chain ends
+        if (k >= nb) { last = -1; break; }                     // max_bounces metallic bounces (or max_bounces == 0): nothing on the chain is shaded
+        float d2 = 2.0f * dot3(cur.normal, cur.dir);
+        f3 rdir = mk3(cur.dir.x - d2 * cur.normal.x, cur.dir.y - d2 * cur.normal.y, cur.dir.z - d2 * cur.normal.z);
+        f3 o = mk3(cur.pos.x + cur.normal.x * 0.01f, cur.pos.y + cur.normal.y * 0.01f, cur.pos.z + cur.normal.z * 0.01f);
+        RayHit rh; RayInt ri;
+        trace_ray<TRAV, Occ, false, true>(s, occ, o, rdir, st.max_steps, rh, ri);
+        c.fetches += ri.fetches; c.rays++;
+        if (rh.material == 0u) {                               // the chain ends in the sky: colorHit of a miss is skyColor(dir)
+            const f3 col = sky_color(s, rh.dir);
+            reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
+            break;
+        }
+        cur = rh;
+    }
+    if (last < 0) {
+        // frag:281-303 with lastIdx = -1: the bounces' secondary rays were traced for nothing -- the reference never traces them
+        c.fetches -= spec_fetches; c.rays -= spec_rays;
+        last = 0;
+    }
+    // the way back: entry j (bounce j - 1) with the reflection gathered behind it, frag:300-303
+#pragma unroll
+    for (int j = NBT; j >= 1; j--) {
+        if (j <= last) {
+            const f3 col = chain_shade(P, codes[j], reflection, (uint32_t)(j - 1));
+            reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
+        }
+    }
+    return chain_shade(P, codes[0], reflection, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -940,7 +1050,9 @@ __device__ __forceinline__ void store_color(const vrt_frame& f, f3 col, size_t i
     }
 }
 
-// MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;
+// MODE 0: write hit records for K2 (split);  1: no secondary rays enabled, shade inline;  4: the megakernel without its bounce loop;
+// MODE 5, 6, 7: the megakernel with the bounce chain as one word per hit (color_main_ray_packed: no stack of hits; what the product
+//         traversals launch) for at most 2 / 5 / VRT_MAX_BOUNCES bounces;
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
@@ -1157,7 +1269,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame); c.have_noise = false;
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
-                col = color_main_ray<TRAV, OccT<kLds>, MODE != 4>(P, occ, c, h);
+                if (MODE >= 5) col = color_main_ray_packed<TRAV, OccT<kLds>, (MODE == 5 ? 2 : (MODE == 6 ? 5 : VRT_MAX_BOUNCES))>(P, occ, c, h);
+                else col = color_main_ray<TRAV, OccT<kLds>, MODE != 4>(P, occ, c, h);
                 if (steps_total && !(P.st.flags & 3u)) steps_total[i] = r.fetches + c.fetches;
                 if (rays_total && !(P.st.flags & 3u)) rays_total[i] = 1u + c.rays;
             }
@@ -1330,7 +1443,7 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
     dim3 block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     // (the product traversals with the tile map's form as a compile-time constant: block_to_tile)
-    constexpr bool kProduct = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_BRICK;
+    constexpr bool kProduct = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK;
     const int map = (kProduct && p.xcd_turn != 1) ? p.xcd_turn : -1;
 #define VRT_LAUNCH_K1(MODE_, TABLE_)                                                                                           \
     do {                                                                                                                       \
@@ -1340,11 +1453,11 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
     } while (0)
     if (p.table) {               // the split form renders one frame per launch and never gets here
         if (p.fused_shade == 1)      VRT_LAUNCH_K1(1, true);
-        else if (p.fused_shade == 2) { if (p.no_bounce) VRT_LAUNCH_K1(4, true); else VRT_LAUNCH_K1(2, true); }
+        else if (p.fused_shade == 2) { if (p.no_bounce) VRT_LAUNCH_K1(4, true); else if (kProduct && p.packed_chain) { if (p.st.max_bounces <= 2) VRT_LAUNCH_K1((kProduct ? 5 : 2), true); else if (p.st.max_bounces <= 5) VRT_LAUNCH_K1((kProduct ? 6 : 2), true); else VRT_LAUNCH_K1((kProduct ? 7 : 2), true); } else VRT_LAUNCH_K1(2, true); }
         else return hipErrorInvalidValue;
     }
     else if (p.fused_shade == 1) VRT_LAUNCH_K1(1, false);
-    else if (p.fused_shade == 2) { if (p.no_bounce) VRT_LAUNCH_K1(4, false); else VRT_LAUNCH_K1(2, false); }
+    else if (p.fused_shade == 2) { if (p.no_bounce) VRT_LAUNCH_K1(4, false); else if (kProduct && p.packed_chain) { if (p.st.max_bounces <= 2) VRT_LAUNCH_K1((kProduct ? 5 : 2), false); else if (p.st.max_bounces <= 5) VRT_LAUNCH_K1((kProduct ? 6 : 2), false); else VRT_LAUNCH_K1((kProduct ? 7 : 2), false); } else VRT_LAUNCH_K1(2, false); }
     else                         VRT_LAUNCH_K1(0, false);
 #undef VRT_LAUNCH_K1
     return hipGetLastError();
@@ -1364,6 +1477,7 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 static int effective_traversal(int t, int fast_loop)
 {
     if (t == VRT_TRAVERSAL_BRICK) return t;
+    if (fast_loop == 2 && (t == VRT_TRAVERSAL_AUTO || t == VRT_TRAVERSAL_DF)) return VRT_TRAVERSAL_DF_FAST_CNT;     // the loops' counting twins
     if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP || t == VRT_TRAVERSAL_DFJ) return t;
     return fast_loop ? VRT_TRAVERSAL_DF_FAST : VRT_TRAVERSAL_DF;        // AUTO / DF
 }
@@ -1372,6 +1486,7 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal, p.fast_loop);
     if (t == VRT_TRAVERSAL_DF_FAST) return launch_primary_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
+    if (t == VRT_TRAVERSAL_DF_FAST_CNT) return launch_primary_t<VRT_TRAVERSAL_DF_FAST_CNT, false>(p, s);
     if (t == VRT_TRAVERSAL_BRICK) return launch_primary_t<VRT_TRAVERSAL_BRICK, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_primary_t<VRT_TRAVERSAL_DF, false>(p, s);
@@ -1383,7 +1498,7 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 hipError_t launch_shade(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal, p.fast_loop);
-    if (t == VRT_TRAVERSAL_DF_FAST) return launch_shade_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
+    if (t == VRT_TRAVERSAL_DF_FAST || t == VRT_TRAVERSAL_DF_FAST_CNT) return launch_shade_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
     if (t == VRT_TRAVERSAL_BRICK) return launch_shade_t<VRT_TRAVERSAL_BRICK, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_shade_t<VRT_TRAVERSAL_DF, false>(p, s);

@@ -184,7 +184,8 @@ struct GeomParams {
     int32_t    fused_shade;    // 1: primary kernel shades inline (no secondary rays enabled); 2: megakernel; 0: split
     int32_t    no_bounce;      // 1: no ray of the launch can bounce (max_bounces == 0 or no metallic voxel in the scene): the megakernel
                                //    without the bounce loop and its scratch stack
-    int32_t    fast_loop;      // 1: AUTO / DF run the hand-written look-up loop (trace_df_fast; the host checked its preconditions)
+    int32_t    packed_chain;   // 1: the megakernel keeps its bounce chain as one word per hit (MODE 5, color_main_ray_packed); 0: the stack of hits
+    int32_t    fast_loop;      // 1: AUTO / DF run the hand-written look-up loop (trace_df_fast; the host checked its preconditions); 2: its counting twins
     int32_t    occ_in_lds;     // 1: stage occ2 + occ3 into LDS, 0: read them through L2
     int32_t    sky_fast;       // 1: waves that cannot hit anything decide their sky texel by vrt_sky.h and write the miss pixel
                                //    without normalising the ray (no diagnostic planes in the launch, W * H < 2^28)

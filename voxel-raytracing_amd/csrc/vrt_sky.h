@@ -50,6 +50,8 @@ inline SkyFastConsts sky_fast_consts(uint32_t w, uint32_t h)
     SkyFastConsts k;
     k.w = 0u; k.h = 0u; k.ku = k.hu = k.kv = k.hv = k.wm1 = k.hm1 = 0.0f; k.tu = k.tv = -1.0f;
     if (w == 0u || h == 0u || w > (1u << 20) || h > (1u << 20)) return k;
+    // (k_primary addresses the RGBA8 copy of the sky with a 32-bit BYTE offset, (y * w + x) << 2: 2^30 texels would wrap it)
+    if ((uint64_t)w * (uint64_t)h >= (1ull << 30)) return k;
     const float fw = (float)w, fh = (float)h;
     // guard = eps * size (the coordinate's own error) + 2 ulps of the product (the spec rounds fract * size once more, the fast
     // path's fused multiply-add rounds once)

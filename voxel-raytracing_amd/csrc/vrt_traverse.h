@@ -42,6 +42,7 @@
 #endif
 #define VRT_TRAVERSAL_BRICK 6     // brick scenes (vrt_scene_from_bricks): DF over a two-level clearance; chosen by AUTO
 #define VRT_TRAVERSAL_DF_FAST 7   // internal: DF through the hand-written look-up loop (trace_df_fast); chosen by the host
+#define VRT_TRAVERSAL_DF_FAST_CNT 8   // internal: the same through the loops' counting twins (VRT_FLAG_MARCHED_COUNTS / VRT_FLAG_LOOKUP_COUNTS)
 
 namespace vrt {
 
@@ -59,6 +60,7 @@ struct VolumeView {
     uint32_t        df_fast;    // 1: the allocation continues with a ninth field, the voxel ids in the same zero-bordered layout
                                 // (field 8), and one byte 0xFF at offset 9 * df_stride, and all of it is addressable with
                                 // 32-bit offsets (trace_df_fast)
+    uint32_t        count_lookups; // 1 (VRT_FLAG_LOOKUP_COUNTS): r.fetches holds the bytes a ray's march asked for instead of its iterations
     uint32_t        count_marched; // 1 (VRT_FLAG_MARCHED_COUNTS): an any-hit ray that is decided a miss without stepping (its clearance covers
                                 // what is left of its budget) reports the iterations it TOOK, not the budget the reference's loop would
                                 // have spent -- the count planes then hold the product march's own work
@@ -821,11 +823,21 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 // Preconditions (checked by the host): v.df_fast, 1 <= maxSteps <= 1024.  The loop runs under the EXEC mask it is entered with.
 // Hazards kept by hand inside the block (gfx950): a DPP source needs two wait states after a vector write, a DPP five
 // after a write of EXEC; a scalar pair written by a vector compare needs two before a vector instruction reads it as mask.
+// Counting twins of the three look-up loops (template CNT; vrt_render_geometry with VRT_FLAG_MARCHED_COUNTS / _LOOKUP_COUNTS): the same
+// instructions plus a per-lane count of the clearance bytes a LIVE lane asks for (the index it loads from is not the 0xFF byte's)
+// and of the voxel ids read at the end of a ray -- the bytes the march really requests, which bench.py reports next to the
+// iterations it performs.  The product kernels are the CNT = false instantiations: not an instruction more.
+#define VRT_CNT_LOOK "v_cmp_ne_u32_e32 vcc, %[sent], v53\n\t" "v_addc_co_u32_e32 %[lk], vcc, 0, %[lk], vcc\n\t"
+#define VRT_CNT_FIND "v_add_u32 %[lk], 1, %[lk]\n\t"
+#define VRT_CNT_OPND , [lk] "+v"(looks)
+#define VRT_CNT_NONE
+#define VRT_CNT_NOOP
+template <bool CNT>
 __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
                                              float& x, float& y, float& z, float dx, float dy, float dz,
                                              float gx, float gy, float gz, float cx, float cy, float cz,
                                              uint32_t idx0, uint32_t voxoff, uint32_t& lmask, uint32_t& material, uint32_t& fetches,
-                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz, uint32_t anyhit, uint32_t pf)
+                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz, uint32_t anyhit, uint32_t pf, uint32_t& looks)
 {
     // the same iteration that also moves the index of the lane's voxel: one more vector instruction per axis under the
     // EXEC mask that is there anyway -- cheaper than recovering the position afterwards for runs of up to four iterations
@@ -880,269 +892,274 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
 #endif
 #define VRT_STR2(x) #x
 #define VRT_STR(x) VRT_STR2(x)
-    asm volatile(
-        ".p2align 6\n\t"
-        ".fill " VRT_STR(VRT_LOOP_PAD_N) ", 4, 0xBF800000\n\t"
-        "s_mov_b32 s60, 0\n\t"
-        "s_movk_i32 s63, 0xff\n\t"
-        // the loop runs under the EXEC mask it is entered with (all 64 lanes for primary rays; the hit lanes of a wave for its
-        // secondary rays): no instruction here may write a lane outside it -- the compiler lets the registers of this block
-        // hold live values of the OTHER lanes of a divergent branch (SIOptimizeVGPRLiveRange)
-        "s_mov_b64 s[68:69], exec\n\t"
-        "v_mov_b32 v53, %[idx0]\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        VRT_F_PREFETCH
-        "10:\n\t"                                                   // ---- look-up: every lane's byte is here ----
-        "s_cmp_eq_u32 %[pf], 0\n\t"
-        "s_cbranch_scc1 8f\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "s_branch 11f\n\t"
-        "8:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "11:\n\t"
-        // any-hit rays (AO, shadow): a lane whose clearance covers what is left of its budget will test nothing but empty voxels
-        // until the budget ends -- it is a miss with fetches = maxSteps, decided here without stepping (a 64-iteration AO ray
-        // that starts in the open: by its first look-up; the fields hold clearances up to 127)
-        "s_cmp_eq_u32 %[any], 0\n\t"
-        "s_cbranch_scc1 111f\n\t"
-        "s_sub_u32 s62, %[maxs], s60\n\t"
-        "v_cmp_le_u32_e32 vcc, s62, v52\n\t"                        // left <= clearance ...
-        "v_cmp_ne_u32_e64 s[64:65], s63, v52\n\t"                   // ... of a lane that is still live
-        "s_and_b64 vcc, vcc, s[64:65]\n\t"
-        "s_cbranch_vccz 111f\n\t"
-        "s_and_saveexec_b64 s[66:67], vcc\n\t"
-        "s_cmp_eq_u32 %[any], 2\n\t"                              // (any == 2: report the iterations taken, VolumeView::count_marched)
-        "s_cselect_b32 s62, s60, %[maxs]\n\t"
-        "v_mov_b32 %[fet], s62\n\t"
-        "v_mov_b32 %[dx], 0\n\t"
-        "v_mov_b32 %[dy], 0\n\t"
-        "v_mov_b32 %[dz], 0\n\t"
-        "v_mov_b32 %[gx], 0\n\t"
-        "v_mov_b32 %[gy], 0\n\t"
-        "v_mov_b32 %[gz], 0\n\t"
-        "v_mov_b32 %[cx], 0\n\t"
-        "v_mov_b32 %[cy], 0\n\t"
-        "v_mov_b32 %[cz], 0\n\t"
-        "v_mov_b32 %[ix], 0\n\t"
-        "v_mov_b32 %[iy], 0\n\t"
-        "v_mov_b32 %[iz], 0\n\t"
-        "v_mov_b32 %[idx0], %[sent]\n\t"
-        "v_mov_b32 v53, %[sent]\n\t"
-        "v_mov_b32 v52, s63\n\t"
-        "s_mov_b64 exec, s[66:67]\n\t"
-        "s_nop 4\n\t"
-        "111:\n\t"
-        "v_cmp_gt_u32_e32 vcc, 2, v52\n\t"                          // 0 (solid / border) or 1 (single iteration) somewhere?
-        "s_cbranch_vccnz 15f\n\t"
-        "v_cmp_gt_u32_e32 vcc, 4, v52\n\t"                          // 2 or 3 somewhere (and nothing below)?
-        "s_cbranch_vccnz 16f\n\t"
-        "s_cmp_eq_u64 s[68:69], -1\n\t"
-        "s_cbranch_scc0 14f\n\t"                                    // a partly filled wave: no DPP reduction (lane 63 may be off)
-        "v_mov_b32 v48, v52\n\t"                                    // wave minimum of the votes: every live lane has >= 4
-        "s_nop 1\n\t"
-        "v_min_u32_dpp v48, v48, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp v48, v48, v48 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp v48, v48, v48 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp v48, v48, v48 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp v48, v48, v48 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp v48, v48, v48 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_sub_u32 s62, %[maxs], s60\n\t"                           // left >= 1
-        "s_nop 0\n\t"
-        "v_readlane_b32 s61, v48, 63\n\t"
-        "s_nop 1\n\t"
-        "s_cmp_eq_u32 s61, s63\n\t"
-        "s_cbranch_scc1 40f\n\t"                                    // nobody is live: done
-        "13:\n\t"
-        "s_min_u32 s61, s61, s62\n\t"
-        "s_cmp_le_u32 s61, 4\n\t"
-        "s_cbranch_scc1 18f\n\t"
-        // ---- a run of kw = s61 >= 5 iterations: plain iterations, then the positions from the sideDist travelled ----
-        "s_add_u32 s60, s60, s61\n\t"                               // i += kw
-        "s_sub_u32 s62, s61, 1\n\t"                                 // plain iterations before the one whose masks are kept
-        "s_cmp_eq_u32 s62, 0\n\t"
-        "s_cbranch_scc1 34f\n\t"
-        "s_bitcmp0_b32 s62, 0\n\t"
-        "s_cbranch_scc1 31f\n\t"
-        VRT_F_EITER
-        "31:\n\t"
-        "s_bitcmp0_b32 s62, 1\n\t"
-        "s_cbranch_scc1 32f\n\t"
-        VRT_F_EITER
-        VRT_F_EITER
-        "32:\n\t"
-        "s_lshr_b32 s62, s62, 2\n\t"                                // quads; SCC = (quads != 0)
-        "s_cbranch_scc0 34f\n\t"
-        "s_sub_u32 s62, s62, 1\n\t"
-        "33:\n\t"
-        VRT_F_EITER
-        VRT_F_EITER
-        VRT_F_EITER
-        VRT_F_EITER
-        "s_sub_u32 s62, s62, 1\n\t"                                 // SCC = borrow: that was the last quad
-        "s_cbranch_scc0 33b\n\t"
-        "34:\n\t"                                                   // the run's last iteration: its EXEC masks are the mask bits
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
-        "v_cmpx_eq_u32 v48, %[x]\n\t"
-        "s_mov_b64 %[kx], exec\n\t"
-        "v_add_f32 %[x], %[x], %[dx]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_cmpx_eq_u32 v48, %[y]\n\t"
-        "s_mov_b64 %[ky], exec\n\t"
-        "v_add_f32 %[y], %[y], %[dy]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_cmpx_eq_u32 v48, %[z]\n\t"
-        "s_mov_b64 %[kz], exec\n\t"
-        "v_add_f32 %[z], %[z], %[dz]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        // ---- where is every lane now?  request its next byte ----
-        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"                     // (legacy: inf * 0 = 0, an axis the ray cannot step along)
-        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t"
-        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t"
-        "v_add_f32 v48, v48, %[cx]\n\t"
-        "v_add_f32 v49, v49, %[cy]\n\t"
-        "v_add_f32 v50, v50, %[cz]\n\t"
-        "v_cvt_rpi_i32_f32 v48, v48\n\t"
-        "v_cvt_rpi_i32_f32 v49, v49\n\t"
-        "v_cvt_rpi_i32_f32 v50, v50\n\t"
-        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t"
-        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t"
-        "v_add_u32 v53, %[idx0], v48\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        VRT_F_PREFETCH
-        "s_cmp_lt_u32 s60, %[maxs]\n\t"
-        "s_cbranch_scc1 10b\n\t"
-        // ---- the budget is spent: the lanes that are still live (their start index is not the 0xFF byte's) stop here ----
-        "19:\n\t"
-        "v_cmp_ne_u32_e32 vcc, %[sent], %[idx0]\n\t"
-        "s_and_saveexec_b64 s[66:67], vcc\n\t"
-        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t"
-        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t"
-        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t"
-        "v_or3_b32 %[lm], v48, v49, v50\n\t"
-        "v_mov_b32 %[fet], s60\n\t"
-        "s_mov_b64 exec, s[66:67]\n\t"
-        "s_branch 40f\n\t"
-        "14:\n\t"                                                   // ---- minimum of a partly filled wave: binary search by votes ----
-        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t"
-        "s_cbranch_vccz 40f\n\t"                                    // nobody is live: done
-        "v_min_u32 v48, 63, v52\n\t"                                // (a finished lane: 63, never below a live one)
-        "s_sub_u32 s62, %[maxs], s60\n\t"
-        "s_mov_b32 s61, 0\n\t"
-        "s_or_b32 s66, s61, 32\n\t"
-        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
-        "s_cmp_eq_u64 vcc, 0\n\t"
-        "s_cselect_b32 s61, s66, s61\n\t"
-        "s_or_b32 s66, s61, 16\n\t"
-        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
-        "s_cmp_eq_u64 vcc, 0\n\t"
-        "s_cselect_b32 s61, s66, s61\n\t"
-        "s_or_b32 s66, s61, 8\n\t"
-        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
-        "s_cmp_eq_u64 vcc, 0\n\t"
-        "s_cselect_b32 s61, s66, s61\n\t"
-        "s_or_b32 s66, s61, 4\n\t"
-        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
-        "s_cmp_eq_u64 vcc, 0\n\t"
-        "s_cselect_b32 s61, s66, s61\n\t"
-        "s_or_b32 s66, s61, 2\n\t"
-        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
-        "s_cmp_eq_u64 vcc, 0\n\t"
-        "s_cselect_b32 s61, s66, s61\n\t"
-        "s_or_b32 s66, s61, 1\n\t"
-        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t"
-        "s_cmp_eq_u64 vcc, 0\n\t"
-        "s_cselect_b32 s61, s66, s61\n\t"
-        "s_branch 13b\n\t"
-        "16:\n\t"                                                   // ---- the smallest vote is 2 or 3 ----
-        "v_cmp_eq_u32_e32 vcc, 2, v52\n\t"
-        "s_sub_u32 s62, %[maxs], s60\n\t"
-        "s_mov_b32 s61, 3\n\t"
-        "s_cbranch_vccz 17f\n\t"
-        "s_mov_b32 s61, 2\n\t"
-        "17:\n\t"
-        "s_min_u32 s61, s61, s62\n\t"
-        "18:\n\t"                                                   // ---- a run of kw = s61 in 1..4 iterations, index moved along ----
-        "s_add_u32 s60, s60, s61\n\t"
-        "s_cmp_eq_u32 s61, 1\n\t"
-        "s_cbranch_scc1 184f\n\t"
-        "s_cmp_eq_u32 s61, 2\n\t"
-        "s_cbranch_scc1 183f\n\t"
-        "s_cmp_eq_u32 s61, 3\n\t"
-        "s_cbranch_scc1 182f\n\t"
-        VRT_F_EITER_IDX
-        "182:\n\t"
-        VRT_F_EITER_IDX
-        "183:\n\t"
-        VRT_F_EITER_IDX
-        "184:\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
-        "v_cmpx_eq_u32 v48, %[x]\n\t"
-        "s_mov_b64 %[kx], exec\n\t"
-        "v_add_f32 %[x], %[x], %[dx]\n\t"
-        "v_add_u32 v53, v53, %[ix]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_cmpx_eq_u32 v48, %[y]\n\t"
-        "s_mov_b64 %[ky], exec\n\t"
-        "v_add_f32 %[y], %[y], %[dy]\n\t"
-        "v_add_u32 v53, v53, %[iy]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_cmpx_eq_u32 v48, %[z]\n\t"
-        "s_mov_b64 %[kz], exec\n\t"
-        "v_add_f32 %[z], %[z], %[dz]\n\t"
-        "v_add_u32 v53, v53, %[iz]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        VRT_F_PREFETCH
-        "s_cmp_lt_u32 s60, %[maxs]\n\t"
-        "s_cbranch_scc1 10b\n\t"
-        "s_branch 19b\n\t"
-        "15:\n\t"                                                   // ---- some lane read 0 or 1 ----
-        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t"
-        "s_mov_b32 s61, 1\n\t"
-        "s_cbranch_vccz 18b\n\t"                                    // only 1s: a single-iteration run
-        "s_and_saveexec_b64 s[66:67], vcc\n\t"                      // lanes that read 0: a solid voxel, or the border
-        "v_add_u32 v48, v53, %[voxoff]\n\t"
-        "global_load_ubyte %[mat], v48, %[base]\n\t"                // the voxel id (0 in the border: the ray has left the volume)
-        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t"
-        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t"
-        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t"
-        "v_or3_b32 %[lm], v48, v49, v50\n\t"
-        "v_mov_b32 %[fet], s60\n\t"
-        "v_mov_b32 %[dx], 0\n\t"
-        "v_mov_b32 %[dy], 0\n\t"
-        "v_mov_b32 %[dz], 0\n\t"
-        "v_mov_b32 %[gx], 0\n\t"
-        "v_mov_b32 %[gy], 0\n\t"
-        "v_mov_b32 %[gz], 0\n\t"
-        "v_mov_b32 %[cx], 0\n\t"
-        "v_mov_b32 %[cy], 0\n\t"
-        "v_mov_b32 %[cz], 0\n\t"
-        "v_mov_b32 %[ix], 0\n\t"
-        "v_mov_b32 %[iy], 0\n\t"
-        "v_mov_b32 %[iz], 0\n\t"
-        "v_mov_b32 %[idx0], %[sent]\n\t"
-        "v_mov_b32 v53, %[sent]\n\t"
-        "v_mov_b32 v52, s63\n\t"
-        "s_mov_b64 exec, s[66:67]\n\t"
-        "s_nop 4\n\t"                                               // EXEC written -> DPP: five wait states
-        "s_branch 11b\n\t"                                          // the other lanes' bytes are still to be looked at
-        "40:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
-          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
-          [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), [fet] "+v"(fetches),
-          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz)
-        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [any] "s"(anyhit), [pf] "s"(pf)
-        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55", "v56",
-          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69");
+#define VRT_F_LOOP(CNT_LOOK, CNT_FIND, CNT_OPND) \
+    asm volatile( \
+        ".p2align 6\n\t" \
+        ".fill " VRT_STR(VRT_LOOP_PAD_N) ", 4, 0xBF800000\n\t" \
+        "s_mov_b32 s60, 0\n\t" \
+        "s_movk_i32 s63, 0xff\n\t" \
+ /* the loop runs under the EXEC mask it is entered with (all 64 lanes for primary rays; the hit lanes of a wave for its */ \
+ /* secondary rays): no instruction here may write a lane outside it -- the compiler lets the registers of this block */ \
+ /* hold live values of the OTHER lanes of a divergent branch (SIOptimizeVGPRLiveRange) */ \
+        "s_mov_b64 s[68:69], exec\n\t" \
+        "v_mov_b32 v53, %[idx0]\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        VRT_F_PREFETCH \
+        "10:\n\t" /* ---- look-up: every lane's byte is here ---- */ \
+        CNT_LOOK \
+        "s_cmp_eq_u32 %[pf], 0\n\t" \
+        "s_cbranch_scc1 8f\n\t" \
+        "s_waitcnt vmcnt(2)\n\t" \
+        "s_branch 11f\n\t" \
+        "8:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "11:\n\t" \
+ /* any-hit rays (AO, shadow): a lane whose clearance covers what is left of its budget will test nothing but empty voxels */ \
+ /* until the budget ends -- it is a miss with fetches = maxSteps, decided here without stepping (a 64-iteration AO ray */ \
+ /* that starts in the open: by its first look-up; the fields hold clearances up to 127) */ \
+        "s_cmp_eq_u32 %[any], 0\n\t" \
+        "s_cbranch_scc1 111f\n\t" \
+        "s_sub_u32 s62, %[maxs], s60\n\t" \
+        "v_cmp_le_u32_e32 vcc, s62, v52\n\t" /* left <= clearance ... */ \
+        "v_cmp_ne_u32_e64 s[64:65], s63, v52\n\t" /* ... of a lane that is still live */ \
+        "s_and_b64 vcc, vcc, s[64:65]\n\t" \
+        "s_cbranch_vccz 111f\n\t" \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" \
+        "s_cmp_eq_u32 %[any], 2\n\t" /* (any == 2: report the iterations taken, VolumeView::count_marched) */ \
+        "s_cselect_b32 s62, s60, %[maxs]\n\t" \
+        "v_mov_b32 %[fet], s62\n\t" \
+        "v_mov_b32 %[dx], 0\n\t" \
+        "v_mov_b32 %[dy], 0\n\t" \
+        "v_mov_b32 %[dz], 0\n\t" \
+        "v_mov_b32 %[gx], 0\n\t" \
+        "v_mov_b32 %[gy], 0\n\t" \
+        "v_mov_b32 %[gz], 0\n\t" \
+        "v_mov_b32 %[cx], 0\n\t" \
+        "v_mov_b32 %[cy], 0\n\t" \
+        "v_mov_b32 %[cz], 0\n\t" \
+        "v_mov_b32 %[ix], 0\n\t" \
+        "v_mov_b32 %[iy], 0\n\t" \
+        "v_mov_b32 %[iz], 0\n\t" \
+        "v_mov_b32 %[idx0], %[sent]\n\t" \
+        "v_mov_b32 v53, %[sent]\n\t" \
+        "v_mov_b32 v52, s63\n\t" \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "s_nop 4\n\t" \
+        "111:\n\t" \
+        "v_cmp_gt_u32_e32 vcc, 2, v52\n\t" /* 0 (solid / border) or 1 (single iteration) somewhere? */ \
+        "s_cbranch_vccnz 15f\n\t" \
+        "v_cmp_gt_u32_e32 vcc, 4, v52\n\t" /* 2 or 3 somewhere (and nothing below)? */ \
+        "s_cbranch_vccnz 16f\n\t" \
+        "s_cmp_eq_u64 s[68:69], -1\n\t" \
+        "s_cbranch_scc0 14f\n\t" /* a partly filled wave: no DPP reduction (lane 63 may be off) */ \
+        "v_mov_b32 v48, v52\n\t" /* wave minimum of the votes: every live lane has >= 4 */ \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v48, v48, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v48, v48, v48 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v48, v48, v48 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v48, v48, v48 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v48, v48, v48 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v48, v48, v48 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+        "s_sub_u32 s62, %[maxs], s60\n\t" /* left >= 1 */ \
+        "s_nop 0\n\t" \
+        "v_readlane_b32 s61, v48, 63\n\t" \
+        "s_nop 1\n\t" \
+        "s_cmp_eq_u32 s61, s63\n\t" \
+        "s_cbranch_scc1 40f\n\t" /* nobody is live: done */ \
+        "13:\n\t" \
+        "s_min_u32 s61, s61, s62\n\t" \
+        "s_cmp_le_u32 s61, 4\n\t" \
+        "s_cbranch_scc1 18f\n\t" \
+ /* ---- a run of kw = s61 >= 5 iterations: plain iterations, then the positions from the sideDist travelled ---- */ \
+        "s_add_u32 s60, s60, s61\n\t" /* i += kw */ \
+        "s_sub_u32 s62, s61, 1\n\t" /* plain iterations before the one whose masks are kept */ \
+        "s_cmp_eq_u32 s62, 0\n\t" \
+        "s_cbranch_scc1 34f\n\t" \
+        "s_bitcmp0_b32 s62, 0\n\t" \
+        "s_cbranch_scc1 31f\n\t" \
+        VRT_F_EITER \
+        "31:\n\t" \
+        "s_bitcmp0_b32 s62, 1\n\t" \
+        "s_cbranch_scc1 32f\n\t" \
+        VRT_F_EITER \
+        VRT_F_EITER \
+        "32:\n\t" \
+        "s_lshr_b32 s62, s62, 2\n\t" /* quads; SCC = (quads != 0) */ \
+        "s_cbranch_scc0 34f\n\t" \
+        "s_sub_u32 s62, s62, 1\n\t" \
+        "33:\n\t" \
+        VRT_F_EITER \
+        VRT_F_EITER \
+        VRT_F_EITER \
+        VRT_F_EITER \
+        "s_sub_u32 s62, s62, 1\n\t" /* SCC = borrow: that was the last quad */ \
+        "s_cbranch_scc0 33b\n\t" \
+        "34:\n\t" /* the run's last iteration: its EXEC masks are the mask bits */ \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t" \
+        "v_cmpx_eq_u32 v48, %[x]\n\t" \
+        "s_mov_b64 %[kx], exec\n\t" \
+        "v_add_f32 %[x], %[x], %[dx]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_cmpx_eq_u32 v48, %[y]\n\t" \
+        "s_mov_b64 %[ky], exec\n\t" \
+        "v_add_f32 %[y], %[y], %[dy]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_cmpx_eq_u32 v48, %[z]\n\t" \
+        "s_mov_b64 %[kz], exec\n\t" \
+        "v_add_f32 %[z], %[z], %[dz]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+ /* ---- where is every lane now?  request its next byte ---- */ \
+        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t" /* (legacy: inf * 0 = 0, an axis the ray cannot step along) */ \
+        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t" \
+        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t" \
+        "v_add_f32 v48, v48, %[cx]\n\t" \
+        "v_add_f32 v49, v49, %[cy]\n\t" \
+        "v_add_f32 v50, v50, %[cz]\n\t" \
+        "v_cvt_rpi_i32_f32 v48, v48\n\t" \
+        "v_cvt_rpi_i32_f32 v49, v49\n\t" \
+        "v_cvt_rpi_i32_f32 v50, v50\n\t" \
+        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t" \
+        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t" \
+        "v_add_u32 v53, %[idx0], v48\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        VRT_F_PREFETCH \
+        "s_cmp_lt_u32 s60, %[maxs]\n\t" \
+        "s_cbranch_scc1 10b\n\t" \
+ /* ---- the budget is spent: the lanes that are still live (their start index is not the 0xFF byte's) stop here ---- */ \
+        "19:\n\t" \
+        "v_cmp_ne_u32_e32 vcc, %[sent], %[idx0]\n\t" \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" \
+        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t" \
+        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t" \
+        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t" \
+        "v_or3_b32 %[lm], v48, v49, v50\n\t" \
+        "v_mov_b32 %[fet], s60\n\t" \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "s_branch 40f\n\t" \
+        "14:\n\t" /* ---- minimum of a partly filled wave: binary search by votes ---- */ \
+        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t" \
+        "s_cbranch_vccz 40f\n\t" /* nobody is live: done */ \
+        "v_min_u32 v48, 63, v52\n\t" /* (a finished lane: 63, never below a live one) */ \
+        "s_sub_u32 s62, %[maxs], s60\n\t" \
+        "s_mov_b32 s61, 0\n\t" \
+        "s_or_b32 s66, s61, 32\n\t" \
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t" \
+        "s_cmp_eq_u64 vcc, 0\n\t" \
+        "s_cselect_b32 s61, s66, s61\n\t" \
+        "s_or_b32 s66, s61, 16\n\t" \
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t" \
+        "s_cmp_eq_u64 vcc, 0\n\t" \
+        "s_cselect_b32 s61, s66, s61\n\t" \
+        "s_or_b32 s66, s61, 8\n\t" \
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t" \
+        "s_cmp_eq_u64 vcc, 0\n\t" \
+        "s_cselect_b32 s61, s66, s61\n\t" \
+        "s_or_b32 s66, s61, 4\n\t" \
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t" \
+        "s_cmp_eq_u64 vcc, 0\n\t" \
+        "s_cselect_b32 s61, s66, s61\n\t" \
+        "s_or_b32 s66, s61, 2\n\t" \
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t" \
+        "s_cmp_eq_u64 vcc, 0\n\t" \
+        "s_cselect_b32 s61, s66, s61\n\t" \
+        "s_or_b32 s66, s61, 1\n\t" \
+        "v_cmp_gt_u32_e32 vcc, s66, v48\n\t" \
+        "s_cmp_eq_u64 vcc, 0\n\t" \
+        "s_cselect_b32 s61, s66, s61\n\t" \
+        "s_branch 13b\n\t" \
+        "16:\n\t" /* ---- the smallest vote is 2 or 3 ---- */ \
+        "v_cmp_eq_u32_e32 vcc, 2, v52\n\t" \
+        "s_sub_u32 s62, %[maxs], s60\n\t" \
+        "s_mov_b32 s61, 3\n\t" \
+        "s_cbranch_vccz 17f\n\t" \
+        "s_mov_b32 s61, 2\n\t" \
+        "17:\n\t" \
+        "s_min_u32 s61, s61, s62\n\t" \
+        "18:\n\t" /* ---- a run of kw = s61 in 1..4 iterations, index moved along ---- */ \
+        "s_add_u32 s60, s60, s61\n\t" \
+        "s_cmp_eq_u32 s61, 1\n\t" \
+        "s_cbranch_scc1 184f\n\t" \
+        "s_cmp_eq_u32 s61, 2\n\t" \
+        "s_cbranch_scc1 183f\n\t" \
+        "s_cmp_eq_u32 s61, 3\n\t" \
+        "s_cbranch_scc1 182f\n\t" \
+        VRT_F_EITER_IDX \
+        "182:\n\t" \
+        VRT_F_EITER_IDX \
+        "183:\n\t" \
+        VRT_F_EITER_IDX \
+        "184:\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t" \
+        "v_cmpx_eq_u32 v48, %[x]\n\t" \
+        "s_mov_b64 %[kx], exec\n\t" \
+        "v_add_f32 %[x], %[x], %[dx]\n\t" \
+        "v_add_u32 v53, v53, %[ix]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_cmpx_eq_u32 v48, %[y]\n\t" \
+        "s_mov_b64 %[ky], exec\n\t" \
+        "v_add_f32 %[y], %[y], %[dy]\n\t" \
+        "v_add_u32 v53, v53, %[iy]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_cmpx_eq_u32 v48, %[z]\n\t" \
+        "s_mov_b64 %[kz], exec\n\t" \
+        "v_add_f32 %[z], %[z], %[dz]\n\t" \
+        "v_add_u32 v53, v53, %[iz]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        VRT_F_PREFETCH \
+        "s_cmp_lt_u32 s60, %[maxs]\n\t" \
+        "s_cbranch_scc1 10b\n\t" \
+        "s_branch 19b\n\t" \
+        "15:\n\t" /* ---- some lane read 0 or 1 ---- */ \
+        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t" \
+        "s_mov_b32 s61, 1\n\t" \
+        "s_cbranch_vccz 18b\n\t" /* only 1s: a single-iteration run */ \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" /* lanes that read 0: a solid voxel, or the border */ \
+        CNT_FIND \
+        "v_add_u32 v48, v53, %[voxoff]\n\t" \
+        "global_load_ubyte %[mat], v48, %[base]\n\t" /* the voxel id (0 in the border: the ray has left the volume) */ \
+        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t" \
+        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t" \
+        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t" \
+        "v_or3_b32 %[lm], v48, v49, v50\n\t" \
+        "v_mov_b32 %[fet], s60\n\t" \
+        "v_mov_b32 %[dx], 0\n\t" \
+        "v_mov_b32 %[dy], 0\n\t" \
+        "v_mov_b32 %[dz], 0\n\t" \
+        "v_mov_b32 %[gx], 0\n\t" \
+        "v_mov_b32 %[gy], 0\n\t" \
+        "v_mov_b32 %[gz], 0\n\t" \
+        "v_mov_b32 %[cx], 0\n\t" \
+        "v_mov_b32 %[cy], 0\n\t" \
+        "v_mov_b32 %[cz], 0\n\t" \
+        "v_mov_b32 %[ix], 0\n\t" \
+        "v_mov_b32 %[iy], 0\n\t" \
+        "v_mov_b32 %[iz], 0\n\t" \
+        "v_mov_b32 %[idx0], %[sent]\n\t" \
+        "v_mov_b32 v53, %[sent]\n\t" \
+        "v_mov_b32 v52, s63\n\t" \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "s_nop 4\n\t" /* EXEC written -> DPP: five wait states */ \
+        "s_branch 11b\n\t" /* the other lanes' bytes are still to be looked at */ \
+        "40:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz), \
+          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz), \
+          [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), [fet] "+v"(fetches), \
+          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz) CNT_OPND \
+        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [any] "s"(anyhit), [pf] "s"(pf) \
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55", "v56", \
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69")
+    if (CNT) { VRT_F_LOOP(VRT_CNT_LOOK, VRT_CNT_FIND, VRT_CNT_OPND); }
+    else { VRT_F_LOOP(VRT_CNT_NONE, VRT_CNT_NONE, VRT_CNT_NOOP); }
 #undef VRT_F_EITER
 #undef VRT_F_EITER_IDX
 #undef VRT_F_PREFETCH
@@ -1169,11 +1186,12 @@ __device__ __forceinline__ void df_fast_loop(const uint8_t* base, uint32_t maxSt
 // df_fast_loop, which counts.  A ray that finds nothing leaves through the border or an open cell as it always did.  Launches
 // that report iteration counts do not come here.
 // Hazards as in df_fast_loop.  Runs under the EXEC mask it is entered with.
+template <bool CNT>
 __device__ __forceinline__ void df_prim_loop(const uint8_t* base, int pw, int pwh, uint32_t sentinel,
                                              float& x, float& y, float& z, float dx, float dy, float dz,
                                              float gx, float gy, float gz, float cx, float cy, float cz,
                                              uint32_t idx0, uint32_t voxoff, uint32_t& lmask, uint32_t& material,
-                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz)
+                                             uint64_t kx, uint64_t ky, uint64_t kz, int incx, int incy, int incz, uint32_t& looks)
 {
 #define VRT_P_EITER_IDX                                          \
         "s_mov_b64 exec, s[68:69]\n\t"                            \
@@ -1209,133 +1227,138 @@ __device__ __forceinline__ void df_prim_loop(const uint8_t* base, int pw, int pw
     // scalars of the block: s61 = run length / trip counter, s63 = 0xFF, s[66:67] = saved EXEC, s[68:69] = EXEC on entry;
     // vectors: v48..v50 temporaries, v52 = the byte read (the lane's clearance; 0xFF: finished), v53 = index of the byte to
     // read next, v54 = the lane's threshold
-    asm volatile(
-        ".p2align 6\n\t"
-        "s_movk_i32 s63, 0xff\n\t"
-        "s_mov_b64 s[68:69], exec\n\t"
-        "v_mov_b32 v53, %[idx0]\n\t"
-        "s_mov_b32 s62, 0\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        "10:\n\t"                                                   // ---- look-up: every lane's byte is here ----
-        // (every look-up is followed by at least one step of every live lane, and no ray has more than 3 x 1024 steps in it: the
-        // count below only ends a wave whose rays cannot step at all -- direction (0, 0, 0): the shader's loop spins to its budget
-        // and misses, and so does a lane that is still live here)
-        "s_add_u32 s62, s62, 1\n\t"
-        "s_cmp_gt_u32 s62, 0x1000\n\t"
-        "s_cbranch_scc1 40f\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "11:\n\t"
-        "v_cmp_gt_u32_e32 vcc, 2, v52\n\t"                          // 0 (solid / border / open) or 1 somewhere?
-        "s_cbranch_vccnz 15f\n\t"
-        "v_cmp_gt_u32_e32 vcc, 5, v52\n\t"                          // 2, 3 or 4 somewhere (and nothing below)?
-        "s_cbranch_vccnz 16f\n\t"
-        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t"                        // everybody has >= 5, or is finished -- anybody live at all?
-        "s_cbranch_vccz 40f\n\t"
-        // ---- a threshold run: T = min(side + (c - 1) delta) (1 - 2^-16); a finished lane (delta 0, c - 1 = 254) gets T below
-        //      every side and takes no step; an axis that cannot step has side = delta = inf and never holds the minimum ----
-        "v_add_u32 v48, -1, v52\n\t"
-        "v_cvt_f32_u32_e32 v48, v48\n\t"
-        "v_fma_f32 v49, v48, %[dx], %[x]\n\t"
-        "v_fma_f32 v50, v48, %[dy], %[y]\n\t"
-        "v_fma_f32 v48, v48, %[dz], %[z]\n\t"
-        "v_min3_f32 v49, v49, v50, v48\n\t"
-        "v_mul_f32 v54, 0x3f7fff00, v49\n\t"
-        VRT_P_AXIS("%[x]", "%[dx]", "2")
-        VRT_P_AXIS("%[y]", "%[dy]", "3")
-        VRT_P_AXIS("%[z]", "%[dz]", "5")
-        // ---- where is every lane now?  request its next byte ----
-        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"                     // (legacy: inf * 0 = 0, an axis the ray cannot step along)
-        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t"
-        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t"
-        "v_add_f32 v48, v48, %[cx]\n\t"
-        "v_add_f32 v49, v49, %[cy]\n\t"
-        "v_add_f32 v50, v50, %[cz]\n\t"
-        "v_cvt_rpi_i32_f32 v48, v48\n\t"
-        "v_cvt_rpi_i32_f32 v49, v49\n\t"
-        "v_cvt_rpi_i32_f32 v50, v50\n\t"
-        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t"
-        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t"
-        "v_add_u32 v53, %[idx0], v48\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        "s_branch 10b\n\t"
-        "16:\n\t"                                                   // ---- the smallest vote is 2, 3 or 4 ----
-        "v_cmp_eq_u32_e32 vcc, 2, v52\n\t"
-        "s_mov_b32 s61, 2\n\t"
-        "s_cbranch_vccnz 18f\n\t"
-        "v_cmp_eq_u32_e32 vcc, 3, v52\n\t"
-        "s_mov_b32 s61, 3\n\t"
-        "s_cbranch_vccnz 18f\n\t"
-        "s_mov_b32 s61, 4\n\t"
-        "18:\n\t"                                                   // ---- a run of s61 in 1..4 merged iterations, index moved along ----
-        "s_cmp_eq_u32 s61, 1\n\t"
-        "s_cbranch_scc1 184f\n\t"
-        "s_cmp_eq_u32 s61, 2\n\t"
-        "s_cbranch_scc1 183f\n\t"
-        "s_cmp_eq_u32 s61, 3\n\t"
-        "s_cbranch_scc1 182f\n\t"
-        VRT_P_EITER_IDX
-        "182:\n\t"
-        VRT_P_EITER_IDX
-        "183:\n\t"
-        VRT_P_EITER_IDX
-        "184:\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"
-        "v_cmpx_eq_u32 v48, %[x]\n\t"
-        "s_mov_b64 %[kx], exec\n\t"
-        "v_add_f32 %[x], %[x], %[dx]\n\t"
-        "v_add_u32 v53, v53, %[ix]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_cmpx_eq_u32 v48, %[y]\n\t"
-        "s_mov_b64 %[ky], exec\n\t"
-        "v_add_f32 %[y], %[y], %[dy]\n\t"
-        "v_add_u32 v53, v53, %[iy]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "v_cmpx_eq_u32 v48, %[z]\n\t"
-        "s_mov_b64 %[kz], exec\n\t"
-        "v_add_f32 %[z], %[z], %[dz]\n\t"
-        "v_add_u32 v53, v53, %[iz]\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        "s_branch 10b\n\t"
-        "15:\n\t"                                                   // ---- some lane read 0 or 1 ----
-        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t"
-        "s_mov_b32 s61, 1\n\t"
-        "s_cbranch_vccz 18b\n\t"                                    // only 1s: a single-iteration run
-        "s_and_saveexec_b64 s[66:67], vcc\n\t"                      // lanes that read 0: a solid voxel, the border, or an open cell
-        "v_add_u32 v48, v53, %[voxoff]\n\t"
-        "global_load_ubyte %[mat], v48, %[base]\n\t"                // the voxel id (0 in the border and in an open cell: a miss)
-        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t"
-        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t"
-        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t"
-        "v_or3_b32 %[lm], v48, v49, v50\n\t"
-        "v_mov_b32 %[dx], 0\n\t"
-        "v_mov_b32 %[dy], 0\n\t"
-        "v_mov_b32 %[dz], 0\n\t"
-        "v_mov_b32 %[gx], 0\n\t"
-        "v_mov_b32 %[gy], 0\n\t"
-        "v_mov_b32 %[gz], 0\n\t"
-        "v_mov_b32 %[cx], 0\n\t"
-        "v_mov_b32 %[cy], 0\n\t"
-        "v_mov_b32 %[cz], 0\n\t"
-        "v_mov_b32 %[ix], 0\n\t"
-        "v_mov_b32 %[iy], 0\n\t"
-        "v_mov_b32 %[iz], 0\n\t"
-        "v_mov_b32 %[idx0], %[sent]\n\t"
-        "v_mov_b32 v53, %[sent]\n\t"
-        "v_mov_b32 v52, s63\n\t"
-        "s_mov_b64 exec, s[66:67]\n\t"
-        "s_branch 11b\n\t"                                          // the other lanes' bytes are still to be looked at
-        "40:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
-          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
-          [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material),
-          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz)
-        : [voxoff] "v"(voxoff), [base] "s"(base), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel)
-        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54",
-          "s61", "s62", "s63", "s66", "s67", "s68", "s69");
+#define VRT_P_LOOP(CNT_LOOK, CNT_FIND, CNT_OPND) \
+    asm volatile( \
+        ".p2align 6\n\t" \
+        "s_movk_i32 s63, 0xff\n\t" \
+        "s_mov_b64 s[68:69], exec\n\t" \
+        "v_mov_b32 v53, %[idx0]\n\t" \
+        "s_mov_b32 s62, 0\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        "10:\n\t" /* ---- look-up: every lane's byte is here ---- */ \
+        CNT_LOOK \
+ /* (every look-up is followed by at least one step of every live lane, and no ray has more than 3 x 1024 steps in it: the */ \
+ /* count below only ends a wave whose rays cannot step at all -- direction (0, 0, 0): the shader's loop spins to its budget */ \
+ /* and misses, and so does a lane that is still live here) */ \
+        "s_add_u32 s62, s62, 1\n\t" \
+        "s_cmp_gt_u32 s62, 0x1000\n\t" \
+        "s_cbranch_scc1 40f\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "11:\n\t" \
+        "v_cmp_gt_u32_e32 vcc, 2, v52\n\t" /* 0 (solid / border / open) or 1 somewhere? */ \
+        "s_cbranch_vccnz 15f\n\t" \
+        "v_cmp_gt_u32_e32 vcc, 5, v52\n\t" /* 2, 3 or 4 somewhere (and nothing below)? */ \
+        "s_cbranch_vccnz 16f\n\t" \
+        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t" /* everybody has >= 5, or is finished -- anybody live at all? */ \
+        "s_cbranch_vccz 40f\n\t" \
+ /* ---- a threshold run: T = min(side + (c - 1) delta) (1 - 2^-16); a finished lane (delta 0, c - 1 = 254) gets T below */ \
+ /* every side and takes no step; an axis that cannot step has side = delta = inf and never holds the minimum ---- */ \
+        "v_add_u32 v48, -1, v52\n\t" \
+        "v_cvt_f32_u32_e32 v48, v48\n\t" \
+        "v_fma_f32 v49, v48, %[dx], %[x]\n\t" \
+        "v_fma_f32 v50, v48, %[dy], %[y]\n\t" \
+        "v_fma_f32 v48, v48, %[dz], %[z]\n\t" \
+        "v_min3_f32 v49, v49, v50, v48\n\t" \
+        "v_mul_f32 v54, 0x3f7fff00, v49\n\t" \
+        VRT_P_AXIS("%[x]", "%[dx]", "2") \
+        VRT_P_AXIS("%[y]", "%[dy]", "3") \
+        VRT_P_AXIS("%[z]", "%[dz]", "5") \
+ /* ---- where is every lane now?  request its next byte ---- */ \
+        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t" /* (legacy: inf * 0 = 0, an axis the ray cannot step along) */ \
+        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t" \
+        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t" \
+        "v_add_f32 v48, v48, %[cx]\n\t" \
+        "v_add_f32 v49, v49, %[cy]\n\t" \
+        "v_add_f32 v50, v50, %[cz]\n\t" \
+        "v_cvt_rpi_i32_f32 v48, v48\n\t" \
+        "v_cvt_rpi_i32_f32 v49, v49\n\t" \
+        "v_cvt_rpi_i32_f32 v50, v50\n\t" \
+        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t" \
+        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t" \
+        "v_add_u32 v53, %[idx0], v48\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        "s_branch 10b\n\t" \
+        "16:\n\t" /* ---- the smallest vote is 2, 3 or 4 ---- */ \
+        "v_cmp_eq_u32_e32 vcc, 2, v52\n\t" \
+        "s_mov_b32 s61, 2\n\t" \
+        "s_cbranch_vccnz 18f\n\t" \
+        "v_cmp_eq_u32_e32 vcc, 3, v52\n\t" \
+        "s_mov_b32 s61, 3\n\t" \
+        "s_cbranch_vccnz 18f\n\t" \
+        "s_mov_b32 s61, 4\n\t" \
+        "18:\n\t" /* ---- a run of s61 in 1..4 merged iterations, index moved along ---- */ \
+        "s_cmp_eq_u32 s61, 1\n\t" \
+        "s_cbranch_scc1 184f\n\t" \
+        "s_cmp_eq_u32 s61, 2\n\t" \
+        "s_cbranch_scc1 183f\n\t" \
+        "s_cmp_eq_u32 s61, 3\n\t" \
+        "s_cbranch_scc1 182f\n\t" \
+        VRT_P_EITER_IDX \
+        "182:\n\t" \
+        VRT_P_EITER_IDX \
+        "183:\n\t" \
+        VRT_P_EITER_IDX \
+        "184:\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t" \
+        "v_cmpx_eq_u32 v48, %[x]\n\t" \
+        "s_mov_b64 %[kx], exec\n\t" \
+        "v_add_f32 %[x], %[x], %[dx]\n\t" \
+        "v_add_u32 v53, v53, %[ix]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_cmpx_eq_u32 v48, %[y]\n\t" \
+        "s_mov_b64 %[ky], exec\n\t" \
+        "v_add_f32 %[y], %[y], %[dy]\n\t" \
+        "v_add_u32 v53, v53, %[iy]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "v_cmpx_eq_u32 v48, %[z]\n\t" \
+        "s_mov_b64 %[kz], exec\n\t" \
+        "v_add_f32 %[z], %[z], %[dz]\n\t" \
+        "v_add_u32 v53, v53, %[iz]\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        "s_branch 10b\n\t" \
+        "15:\n\t" /* ---- some lane read 0 or 1 ---- */ \
+        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t" \
+        "s_mov_b32 s61, 1\n\t" \
+        "s_cbranch_vccz 18b\n\t" /* only 1s: a single-iteration run */ \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" /* lanes that read 0: a solid voxel, the border, or an open cell */ \
+        CNT_FIND \
+        "v_add_u32 v48, v53, %[voxoff]\n\t" \
+        "global_load_ubyte %[mat], v48, %[base]\n\t" /* the voxel id (0 in the border and in an open cell: a miss) */ \
+        "v_cndmask_b32_e64 v48, 0, 1, %[kx]\n\t" \
+        "v_cndmask_b32_e64 v49, 0, 2, %[ky]\n\t" \
+        "v_cndmask_b32_e64 v50, 0, 4, %[kz]\n\t" \
+        "v_or3_b32 %[lm], v48, v49, v50\n\t" \
+        "v_mov_b32 %[dx], 0\n\t" \
+        "v_mov_b32 %[dy], 0\n\t" \
+        "v_mov_b32 %[dz], 0\n\t" \
+        "v_mov_b32 %[gx], 0\n\t" \
+        "v_mov_b32 %[gy], 0\n\t" \
+        "v_mov_b32 %[gz], 0\n\t" \
+        "v_mov_b32 %[cx], 0\n\t" \
+        "v_mov_b32 %[cy], 0\n\t" \
+        "v_mov_b32 %[cz], 0\n\t" \
+        "v_mov_b32 %[ix], 0\n\t" \
+        "v_mov_b32 %[iy], 0\n\t" \
+        "v_mov_b32 %[iz], 0\n\t" \
+        "v_mov_b32 %[idx0], %[sent]\n\t" \
+        "v_mov_b32 v53, %[sent]\n\t" \
+        "v_mov_b32 v52, s63\n\t" \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "s_branch 11b\n\t" /* the other lanes' bytes are still to be looked at */ \
+        "40:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz), \
+          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz), \
+          [idx0] "+v"(idx0), [lm] "+v"(lmask), [mat] "+v"(material), \
+          [kx] "+s"(kx), [ky] "+s"(ky), [kz] "+s"(kz), [ix] "+v"(incx), [iy] "+v"(incy), [iz] "+v"(incz) CNT_OPND \
+        : [voxoff] "v"(voxoff), [base] "s"(base), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel) \
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", \
+          "s61", "s62", "s63", "s66", "s67", "s68", "s69")
+    if (CNT) { VRT_P_LOOP(VRT_CNT_LOOK, VRT_CNT_FIND, VRT_CNT_OPND); }
+    else { VRT_P_LOOP(VRT_CNT_NONE, VRT_CNT_NONE, VRT_CNT_NOOP); }
 #undef VRT_P_AXIS
 #undef VRT_P_EITER_IDX
 }
@@ -1359,10 +1382,11 @@ __device__ __forceinline__ void df_prim_loop(const uint8_t* base, int pw, int pw
 #ifndef VRT_OWN_CAP_BRICK
 #define VRT_OWN_CAP_BRICK 8          // ... in the brick march, whose look-ups cost more (trace_brick_own: 5.07 ms at 4, 5.00 at 8)
 #endif
+template <bool CNT>
 __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
                                             float& x, float& y, float& z, float dx, float dy, float dz,
                                             float gx, float gy, float gz, float cx, float cy, float cz,
-                                            uint32_t idx0, uint32_t voxoff, uint32_t& material, uint32_t& fetches, uint32_t marched)
+                                            uint32_t idx0, uint32_t voxoff, uint32_t& material, uint32_t& fetches, uint32_t marched, uint32_t& looks)
 {
     // vectors of the block: v48..v50 temporaries, v52 the byte read, v53 its index, v54 = i (iterations this lane has taken),
     // v55 = iterations this lane may still take before it has to look again; scalars: s63 = 0xFF, s[64:65] lanes with some left,
@@ -1396,78 +1420,86 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
         "v_mov_b32 %[idx0], %[sent]\n\t"                          \
         "v_mov_b32 v53, %[sent]\n\t"                              \
         "v_mov_b32 v52, s63\n\t"
-    asm volatile(
-        ".p2align 6\n\t"
-        "s_movk_i32 s63, 0xff\n\t"
-        "s_mov_b64 s[68:69], exec\n\t"
-        "v_mov_b32 v53, %[idx0]\n\t"
-        "v_mov_b32 v54, 0\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        "10:\n\t"                                                   // ---- every lane's byte is here ----
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t"                        // solid, border or open cell: the lane ends here
-        "s_cbranch_vccz 12f\n\t"
-        "s_and_saveexec_b64 s[66:67], vcc\n\t"
-        "v_add_u32 v48, v53, %[voxoff]\n\t"
-        "global_load_ubyte %[mat], v48, %[base]\n\t"              // the voxel id says which
-        "v_mov_b32 %[fet], v54\n\t"
-        VRT_A_FINISH
-        "s_mov_b64 exec, s[66:67]\n\t"
-        "12:\n\t"
-        "v_cmp_ne_u32_e64 s[64:65], s63, v52\n\t"                 // live lanes ...
-        "v_sub_u32 v48, %[maxs], v54\n\t"                         // ... what is left of their budget ...
-        "s_nop 0\n\t"
-        "v_cmp_le_u32_e32 vcc, v48, v52\n\t"                      // ... and whether the clearance covers it: a miss at the budget
-        "s_and_b64 vcc, vcc, s[64:65]\n\t"
-        "s_cbranch_vccz 13f\n\t"
-        "s_and_saveexec_b64 s[66:67], vcc\n\t"
-        "v_mov_b32 %[fet], %[maxs]\n\t"
-        "s_cmp_eq_u32 %[mar], 0\n\t"                            // (VolumeView::count_marched: the iterations this lane took)
-        "s_cbranch_scc1 131f\n\t"
-        "v_mov_b32 %[fet], v54\n\t"
-        "131:\n\t"
-        VRT_A_FINISH
-        "s_mov_b64 exec, s[66:67]\n\t"
-        "13:\n\t"
-        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t"                      // who is live now
-        "s_cbranch_vccz 40f\n\t"                                  // nobody: done
-        "v_cndmask_b32_e32 v55, 0, v52, vcc\n\t"                  // iterations the lane may take: its clearance (0 for a finished lane)
-        "v_min_u32 v55, " VRT_STR(VRT_OWN_CAP) ", v55\n\t"          // ... but no more than a few: the others wait for the longest
-        "v_add_u32 v54, v54, v55\n\t"                             // it will take them all before the next look
-        "20:\n\t"                                                   // ---- iterations for the lanes that have some left (four per trip) ----
-        VRT_A_ITER VRT_A_ITER VRT_A_ITER VRT_A_ITER
-        "s_branch 20b\n\t"
-        "30:\n\t"                                                   // ---- where is every lane now?  request its next byte ----
-        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t"
-        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t"
-        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t"
-        "v_add_f32 v48, v48, %[cx]\n\t"
-        "v_add_f32 v49, v49, %[cy]\n\t"
-        "v_add_f32 v50, v50, %[cz]\n\t"
-        "v_cvt_rpi_i32_f32 v48, v48\n\t"
-        "v_cvt_rpi_i32_f32 v49, v49\n\t"
-        "v_cvt_rpi_i32_f32 v50, v50\n\t"
-        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t"
-        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t"
-        "v_add_u32 v53, %[idx0], v48\n\t"
-        "global_load_ubyte v52, v53, %[base]\n\t"
-        "s_branch 10b\n\t"
-        "40:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 exec, s[68:69]\n\t"
-        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz),
-          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz),
-          [idx0] "+v"(idx0), [mat] "+v"(material), [fet] "+v"(fetches)
-        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [mar] "s"(marched)
-        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55",
-          "s63", "s64", "s65", "s66", "s67", "s68", "s69");
+#define VRT_A_LOOP(CNT_LOOK, CNT_FIND, CNT_OPND) \
+    asm volatile( \
+        ".p2align 6\n\t" \
+        "s_movk_i32 s63, 0xff\n\t" \
+        "s_mov_b64 s[68:69], exec\n\t" \
+        "v_mov_b32 v53, %[idx0]\n\t" \
+        "v_mov_b32 v54, 0\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        "10:\n\t" /* ---- every lane's byte is here ---- */ \
+        CNT_LOOK \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t" /* solid, border or open cell: the lane ends here */ \
+        "s_cbranch_vccz 12f\n\t" \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" \
+        "v_add_u32 v48, v53, %[voxoff]\n\t" \
+        CNT_FIND \
+        "global_load_ubyte %[mat], v48, %[base]\n\t" /* the voxel id says which */ \
+        "v_mov_b32 %[fet], v54\n\t" \
+        VRT_A_FINISH \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "12:\n\t" \
+        "v_cmp_ne_u32_e64 s[64:65], s63, v52\n\t" /* live lanes ... */ \
+        "v_sub_u32 v48, %[maxs], v54\n\t" /* ... what is left of their budget ... */ \
+        "s_nop 0\n\t" \
+        "v_cmp_le_u32_e32 vcc, v48, v52\n\t" /* ... and whether the clearance covers it: a miss at the budget */ \
+        "s_and_b64 vcc, vcc, s[64:65]\n\t" \
+        "s_cbranch_vccz 13f\n\t" \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" \
+        "v_mov_b32 %[fet], %[maxs]\n\t" \
+        "s_cmp_eq_u32 %[mar], 0\n\t" /* (VolumeView::count_marched: the iterations this lane took) */ \
+        "s_cbranch_scc1 131f\n\t" \
+        "v_mov_b32 %[fet], v54\n\t" \
+        "131:\n\t" \
+        VRT_A_FINISH \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "13:\n\t" \
+        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t" /* who is live now */ \
+        "s_cbranch_vccz 40f\n\t" /* nobody: done */ \
+        "v_cndmask_b32_e32 v55, 0, v52, vcc\n\t" /* iterations the lane may take: its clearance (0 for a finished lane) */ \
+        "v_min_u32 v55, " VRT_STR(VRT_OWN_CAP) ", v55\n\t" /* ... but no more than a few: the others wait for the longest */ \
+        "v_add_u32 v54, v54, v55\n\t" /* it will take them all before the next look */ \
+        "20:\n\t" /* ---- iterations for the lanes that have some left (four per trip) ---- */ \
+        VRT_A_ITER VRT_A_ITER VRT_A_ITER VRT_A_ITER \
+        "s_branch 20b\n\t" \
+        "30:\n\t" /* ---- where is every lane now?  request its next byte ---- */ \
+        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t" \
+        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t" \
+        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t" \
+        "v_add_f32 v48, v48, %[cx]\n\t" \
+        "v_add_f32 v49, v49, %[cy]\n\t" \
+        "v_add_f32 v50, v50, %[cz]\n\t" \
+        "v_cvt_rpi_i32_f32 v48, v48\n\t" \
+        "v_cvt_rpi_i32_f32 v49, v49\n\t" \
+        "v_cvt_rpi_i32_f32 v50, v50\n\t" \
+        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t" \
+        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t" \
+        "v_add_u32 v53, %[idx0], v48\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        "s_branch 10b\n\t" \
+        "40:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz), \
+          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz), \
+          [idx0] "+v"(idx0), [mat] "+v"(material), [fet] "+v"(fetches) CNT_OPND \
+        : [voxoff] "v"(voxoff), [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [mar] "s"(marched) \
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55", \
+          "s63", "s64", "s65", "s66", "s67", "s68", "s69")
+    if (CNT) { VRT_A_LOOP(VRT_CNT_LOOK, VRT_CNT_FIND, VRT_CNT_OPND); }
+    else { VRT_A_LOOP(VRT_CNT_NONE, VRT_CNT_NONE, VRT_CNT_NOOP); }
 #undef VRT_A_FINISH
 #undef VRT_A_ITER
 }
 
 // PF: the look-ups ask for the two neighbouring rows as well (secondary rays: VRT_F_PREFETCH)
 // OWN: every lane spends its own clearance (df_any_loop; any-hit rays)
-template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false>
+// CNT: the counting twins of the loops (VRT_TRAVERSAL_DF_FAST_CNT): r.fetches = what the march DID for this ray -- the iterations it took
+//      (a threshold run's per-axis steps, which is the same number unless two axes tie), or with VolumeView::count_lookups the bytes it
+//      asked for (clearance bytes of live lanes, times three where the look-ups prefetch, + the voxel id at the end)
+template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false, bool CNT = false>
 __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -1489,9 +1521,10 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     float dx = done0 ? 0.0f : s.dx, dy = done0 ? 0.0f : s.dy, dz = done0 ? 0.0f : s.dz;
     float gx = (!done0 && s.dx < kInf) ? dir.x : 0.0f, gy = (!done0 && s.dy < kInf) ? dir.y : 0.0f, gz = (!done0 && s.dz < kInf) ? dir.z : 0.0f;
     float cx = gx != 0.0f ? -(s.sdx * gx) : 0.0f, cy = gy != 0.0f ? -(s.sdy * gy) : 0.0f, cz = gz != 0.0f ? -(s.sdz * gz) : 0.0f;
+    const float gx0 = gx, gy0 = gy, gz0 = gz, cx0 = cx, cy0 = cy, cz0 = cz;     // (CNT: the loops zero a finished lane's copies)
     const uint32_t idx0 = done0 ? sentinel : octoff + (uint32_t)df_index(v, s.mx, s.my, s.mz);
     const uint32_t voxoff = 8u * stride - (octoff - bias);
-    uint32_t lmask = s.mask, material = 0u, fetches = 0u;
+    uint32_t lmask = s.mask, material = 0u, fetches = 0u, looks = 0u;
     const uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
     float x = s.sdx, y = s.sdy, z = s.sdz;
     // what one step along an axis adds to the index (0 for a lane that never enters the volume)
@@ -1509,24 +1542,48 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
         const float bound = s.tspan * ((fabsf(dir.x) + fabsf(dir.y)) + fabsf(dir.z)) * 1.001f + 8.0f;
         thresh = __ballot(!done0 && !(bound < (float)maxSteps)) == 0ull;
     }
+    bool prefetching = false;
     if (thresh) {
-        df_prim_loop(base, __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh), (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel),
-                     x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, kx, ky, kz, incx, incy, incz);
+        df_prim_loop<CNT>(base, __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh), (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel),
+                          x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, kx, ky, kz, incx, incy, incz, looks);
+        if (CNT) {
+            // the iterations of a march that does not count them: the steps each axis has taken, from the sideDist travelled (the
+            // position recovery's own formula); two axes that tie step in ONE iteration of the shader's loop and count twice here
+            float qx, qy, qz;
+            asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(qx) : "v"(x), "v"(gx0));
+            asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(qy) : "v"(y), "v"(gy0));
+            asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(qz) : "v"(z), "v"(gz0));
+            int nx, ny, nz;
+            asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(nx) : "v"(qx + cx0));
+            asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(ny) : "v"(qy + cy0));
+            asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(nz) : "v"(qz + cz0));
+            fetches = (uint32_t)((nx < 0 ? -nx : nx) + (ny < 0 ? -ny : ny) + (nz < 0 ? -nz : nz));
+        }
     } else if (ANYHIT && OWN && __builtin_amdgcn_readfirstlane((int)v.df_own) != 0) {
-        df_any_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, material, fetches,
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)v.count_marched));
-    } else
-    df_fast_loop(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
-                 (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
-                 incx, incy, incz, ANYHIT ? 1u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(v.count_marched != 0u)) : 0u, PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v.df_prefetch) : 0u);
+        df_any_loop<CNT>(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, material, fetches,
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)v.count_marched), looks);
+    } else {
+        const uint32_t pf = PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v.df_prefetch) : 0u;
+        prefetching = pf != 0u;
+        df_fast_loop<CNT>(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz, idx0, voxoff, lmask, material, fetches, kx, ky, kz,
+                          incx, incy, incz, ANYHIT ? 1u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(v.count_marched != 0u)) : 0u, pf, looks);
+    }
     s.sdx = x; s.sdy = y; s.sdz = z;
-    finish(s, material, lmask, fetches + (material != 0u ? 1u : 0u), r);
-    (void)stats;
+    uint32_t reported = fetches + (material != 0u ? 1u : 0u);
+    if (CNT && v.count_lookups != 0u) {
+        // bytes asked for: one clearance byte per look-up of a live lane and the voxel id where a lane read 0 (the loops count both
+        // in one register); where the look-ups prefetch the two neighbouring rows, three bytes each (the id then counts thrice too:
+        // an upper bound, two bytes per ray above the truth)
+        reported = done0 ? 0u : (prefetching ? 3u * looks : looks);
+    }
+    finish(s, material, lmask, reported, r);
+    (void)stats; (void)gx0; (void)gy0; (void)gz0; (void)cx0; (void)cy0; (void)cz0;
 }
 #else
 // host pass of a .hip file / the host build of the unit tests: parsed, never run (the loop is gfx950 assembly)
-template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false>
+template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false, bool CNT = false>
 VRT_HD void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 #endif
 
@@ -2204,6 +2261,9 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
         trace_df_fast<NoStats, ANYHIT, PF, OWN>(v, start, dir, maxSteps, r, ns);
+    } else if (TRAV == VRT_TRAVERSAL_DF_FAST_CNT) {
+        NoStats ns;
+        trace_df_fast<NoStats, ANYHIT, PF, OWN, true>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF) {
         NoStats ns;
         trace_df<NoStats, AHEAD>(v, start, dir, maxSteps, r, ns);

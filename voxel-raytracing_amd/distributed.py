@@ -281,14 +281,15 @@ class ShardedBatch:
         import torch
         if denoise and not stage._settings.denoiserSettings.enable:
             raise ValueError("ShardedBatch(denoise=True) with the denoiser switched off in the stage's settings (denoiserSettings.enable)")
-        if direct and int(nranks) > 1 and getattr(stage, "_debug", False):
-            raise ValueError("ShardedBatch(direct=...) launches write the frames' planes through its own frame table, which carries no "
-                             "diagnostic planes (hit_voxel, steps_*): use direct=False with a debug_planes stage")
         # N = 1: the same call returns filtered frames as at N > 1 -- the unsharded denoiser on every frame of the batch (step())
         self._denoise_alone = bool(denoise) and int(nranks) <= 1
         self.denoise = bool(denoise) and int(nranks) > 1
         if self.denoise:
             direct = False                                     # the colour that travels is the denoiser's output, not K1's
+        # (the EFFECTIVE direct: a sharded denoising batch never uses the direct frame table, whatever the argument says)
+        if direct and int(nranks) > 1 and getattr(stage, "_debug", False):
+            raise ValueError("ShardedBatch(direct=...) launches write the frames' planes through its own frame table, which carries no "
+                             "diagnostic planes (hit_voxel, steps_*): use direct=False with a debug_planes stage")
         self.stage, self.F = stage, int(n_frames)
         self.host_staged = bool(host_staged)       # collective through host memory (gloo rehearsal of the N > 1 path on one GPU)
         self.side_unpack = bool(side_unpack) and not self.host_staged      # assemble received frames on a second stream
