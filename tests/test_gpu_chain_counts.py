@@ -128,5 +128,6 @@ def test_counting_twins(vrt, oracle, engine):
             rays = twin["rays_total"].astype(np.int64)
             traced = b > 0
             assert (lk[traced] >= 1).all() and (lk <= 3 * (np.maximum(a, b) + 2 * rays)).all(), (name, pos, "look-ups: at least one per traced pixel, at most three bytes per iteration + id")
-            assert lk.sum() < b.sum(), (name, pos, "the clearance runs are what keeps the march from asking per iteration")
+            if not ties:
+                assert lk.sum() < b.sum(), (name, pos, "the clearance runs are what keeps the march from asking per iteration")
     sc.destroy()

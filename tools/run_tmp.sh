@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_chain_counts.py -x -q -m gpu -k twins 2>&1 | grep -E "DIAG|passed|failed" | head
-timeout -k 10 600 python tools/exp_r4_ao_util.py 2>&1 | grep UTIL
+timeout -k 10 1100 python -m pytest tests -q -m gpu -x 2>&1 | tail -12

@@ -49,7 +49,7 @@ struct DevOptions {
     int fast_loop = 1;         // AUTO / DF through the hand-written look-up loop
     int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
     int packed_bounces = 1;    // the megakernel's bounce chain as one word per hit (no stack of hits in scratch)
-    int ao_thresh = 1;         // AO rays through the threshold loop (df_ao_loop), the counting loop only where the step bound straddles the budget
+    int ao_batch = 1;          // the hand-written loop takes a lane's AO rays two at a time, back to back (df_ao_batch_loop)
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
     int thresh_runs = 1;       // primary rays through df_prim_loop (long runs by threshold)
     int hit_table = 1;         // launches without secondary rays take a hit's colour from the table of colorHit() over materials x normals
@@ -67,7 +67,7 @@ static const OptName kOptNames[] = {
     {"tile_tags", "VRT_TILE_TAGS", &DevOptions::tile_tags}, {"box_rect", "VRT_BOX_RECT", &DevOptions::box_rect},
     {"xcd_regions", "VRT_XCD_REGIONS", &DevOptions::xcd_regions}, {"fast_loop", "VRT_FAST_LOOP", &DevOptions::fast_loop},
     {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
-    {"packed_bounces", "VRT_PACKED_BOUNCES", &DevOptions::packed_bounces}, {"ao_thresh", "VRT_AO_THRESH", &DevOptions::ao_thresh},
+    {"packed_bounces", "VRT_PACKED_BOUNCES", &DevOptions::packed_bounces}, {"ao_batch", "VRT_AO_BATCH", &DevOptions::ao_batch},
     {"hit_table", "VRT_HIT_TABLE", &DevOptions::hit_table},
     {"thresh_runs", "VRT_THRESH_RUNS", &DevOptions::thresh_runs}, {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
     {"denoise_verified", "VRT_DENOISE_VERIFIED", &DevOptions::denoise_verified}, {"denoise_guard_div8", "VRT_DENOISE_GUARD_DIV8", &DevOptions::denoise_guard_div8},
@@ -1006,6 +1006,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     // 1: nothing but primary rays; 2: megakernel (default); 0: split K1 -> records -> K2 (VRT_FLAG_SPLIT_KERNELS)
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && (st->max_bounces == 0 || !s->metallic_voxels)) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
     p.no_bounce = ((st->max_bounces == 0 || !s->metallic_voxels) && c->opt.no_bounce_kernel) ? 1 : 0;
+    p.sc.vol.ao_batch = (c->opt.ao_batch && p.sc.vol.df_own) ? 1u : 0u;
     p.packed_chain = (c->opt.packed_bounces && st->ao_samples <= 0xFFFFu) ? 1 : 0;     // (16 bits of a chain word count the AO rays that hit)
     // default traversal and budgets the recovery of positions from sideDist is exact for: the hand-written look-up loop
     // (vrt_traverse.h trace_df_fast) for every ray of the frame
@@ -1016,7 +1017,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         bool ok = want && df && s->d.vol.df_fast && st->max_steps >= 1 && st->max_steps <= 1024 && p.tile_h == 8 &&
                   !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (!sec || st->ao_samples == 0 || (st->ao_steps >= 1 && st->ao_steps <= 1024));
         for (int f = 0; f < n && ok; f++) ok = frames[f].hit_voxel == nullptr;      // the fast loop keeps no mapPos: no hit_voxel plane
-        p.fast_loop = ok ? ((st->flags & VRT_FLAG_MARCHED_COUNTS) ? 2 : 1) : 0;      // (2: the loops' counting twins)
+        p.fast_loop = ok ? ((counts || (st->flags & VRT_FLAG_MARCHED_COUNTS)) ? 2 : 1) : 0;      // (2: the loops' counting twins -- every launch that fills iteration-count planes)
         // ... and the primary rays' long runs by threshold (df_prim_loop): launches that report no iteration counts (the loop keeps
         // none), axis step counts the position recovery is exact for, a budget worth not counting
         const int dmax = s->d.vol.W > s->d.vol.H ? (s->d.vol.W > s->d.vol.D ? s->d.vol.W : s->d.vol.D) : (s->d.vol.H > s->d.vol.D ? s->d.vol.H : s->d.vol.D);

@@ -421,7 +421,11 @@ __device__ __forceinline__ float decode_snorm8(int32_t c)
 
 // pc: the push block of the pixel's frame; noise: the pixel's blue-noise texel, decoded on first use (it is the same for
 // every AO sample and every bounce of the pixel)
-struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; f3 noise; bool have_noise; };
+// (kernels of VRT_TRAVERSAL_DF_FAST never fill iteration-count planes -- vrt_api.hip sends every launch that has them to the counting twins,
+// VRT_TRAVERSAL_DF_FAST_CNT -- so for them `fetches` is dead and the compiler drops it: VRT_COUNTS(TRAV))
+#define VRT_COUNTS(TRAV) ((TRAV) != VRT_TRAVERSAL_DF_FAST)
+struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; f3 noise; bool have_noise;
+                uint32_t ldsw; };    // ldsw: byte address of the wave's VRT_AO_SLOT bytes of LDS (df_ao_pool_loop): kernels that trace AO rays through the hand-written loop
 
 // skyColor, voxel_volume.frag:98-105
 __device__ __forceinline__ f3 sky_color(const DevScene& s, f3 d)
@@ -589,8 +593,40 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
     const DevScene& s = P.sc;
     const vrt_settings& st = P.st;
     ambient = 0.0f; ao_hits = 0u;
+    constexpr bool kBatch = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT;
     if (!SEC || st.ao_samples == 0) {
         ambient = 1.0f;
+    } else if (kBatch && __builtin_amdgcn_readfirstlane((int)s.vol.ao_batch) != 0) {
+        // the hand-written loop: the AO rays of the wave's pixels from a pool in LDS that every lane draws on (df_ao_pool_loop) --
+        // sample after sample each lane writes its pixel's ray into its column, and whichever lane is free traces it and reports
+        // to the column's counter; which lane traces a ray changes nothing about what the ray finds
+        constexpr bool kCnt = TRAV == VRT_TRAVERSAL_DF_FAST_CNT;
+        const uint32_t ldsw = c.ldsw;
+        const uint64_t act = __ballot(true);
+        const uint32_t col = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        const uint32_t nact = (uint32_t)__builtin_popcountll(act);
+        __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 2816u + col * 4u);
+        cnt[0] = 0u;
+        if (kCnt) cnt[64] = 0u;
+        AoLane lane;
+        ao_lane_rest(s.vol, lane);
+        uint32_t next = 0u, looks = 0u;
+        for (uint32_t i = 0; i < st.ao_samples; i++) {
+            f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
+            f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
+            f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
+            AoRay a;
+            ao_ray_setup(s.vol, o, dir, a);
+            ao_ray_store(ldsw, col, a);
+            next = 0u;
+            trace_ao_pool<kCnt>(s.vol, lane, ldsw, nact, i + 1u < st.ao_samples ? 1u : 0u, next, st.ao_steps, looks);
+        }
+        ao_hits = cnt[0];
+        c.rays += st.ao_samples;
+        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : cnt[64];
+        // calcAmbient's sum (frag:219-222): one addition of 1 / aoSamples per ray that hit -- the value depends on their number only
+        float sample_frac = 1.0f / (float)st.ao_samples;
+        for (uint32_t q = 0; q < ao_hits; q++) ambient += sample_frac;
     } else {
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
@@ -599,8 +635,10 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
             f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
             RayInt r;
             // AO rays have a 64-iteration budget: too short for jumps to pay, and budget ties would force re-traces
-            trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV), decltype(occ.o2), false, true, false, true>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);   // (no prefetch: AO rays point every way, three gathers instead of one measured +18 %)
-            c.fetches += r.fetches; c.rays++;
+            // (the hand-written loop's kernels: every lane its own clearance is the batched path above; here the wave's smallest)
+            trace_int<((TRAV == VRT_TRAVERSAL_JUMP || TRAV == VRT_TRAVERSAL_DFJ) ? VRT_TRAVERSAL_DF : TRAV), decltype(occ.o2), false, true, false, !kBatch>(s.vol, occ.o2, occ.o3, o, dir, st.ao_steps, r);   // (no prefetch: AO rays point every way, three gathers instead of one measured +18 %)
+            if (VRT_COUNTS(TRAV)) c.fetches += r.fetches;
+            c.rays++;
             if (r.material != 0) { ambient += sample_frac; ao_hits++; }
         }
     }
@@ -610,7 +648,8 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
         f3 o = mk3(pos.x + normal.x * 0.01f, pos.y + normal.y * 0.01f, pos.z + normal.z * 0.01f);
         RayInt r;
         trace_int<TRAV, decltype(occ.o2), false, true, true>(s.vol, occ.o2, occ.o3, o, L, st.max_steps, r);      // traceRayHit: only "did it hit" is used
-        c.fetches += r.fetches; c.rays++;
+        if (VRT_COUNTS(TRAV)) c.fetches += r.fetches;
+        c.rays++;
         shadowed = r.material != 0;
     }
 }
@@ -682,7 +721,8 @@ __device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, cons
             f3 o = mk3(last.pos.x + last.normal.x * 0.01f, last.pos.y + last.normal.y * 0.01f, last.pos.z + last.normal.z * 0.01f);
             RayHit rh; RayInt ri;
             trace_ray<TRAV, Occ, false, true>(s, occ, o, rdir, st.max_steps, rh, ri);
-            c.fetches += ri.fetches; c.rays++;
+            if (VRT_COUNTS(TRAV)) c.fetches += ri.fetches;
+            c.rays++;
             bounces[i] = rh;
             last = rh;
             if (last.material == 0 || s.palette[last.material].metallic <= 0.0f) { last_idx = i; break; }
@@ -755,14 +795,15 @@ __device__ f3 color_main_ray_packed(const GeomParams& P, const Occ occ, PixCtx& 
         last = k;
         const bool metal = s.palette[cur.material].metallic > 0.0f;
         if (!metal) break;                                     // (k = 0: no chain at all; k > 0: the chain ends on a hit that does not reflect)
-        if (k > 0) { spec_fetches += c.fetches - f0; spec_rays += c.rays - r0; }    // a metallic bounce: shaded only if the chain ends
+        if (k > 0) { if (VRT_COUNTS(TRAV)) spec_fetches += c.fetches - f0; spec_rays += c.rays - r0; }    // a metallic bounce: shaded only if the chain ends
         if (k >= nb) { last = -1; break; }                     // max_bounces metallic bounces (or max_bounces == 0): nothing on the chain is shaded
         float d2 = 2.0f * dot3(cur.normal, cur.dir);
         f3 rdir = mk3(cur.dir.x - d2 * cur.normal.x, cur.dir.y - d2 * cur.normal.y, cur.dir.z - d2 * cur.normal.z);
         f3 o = mk3(cur.pos.x + cur.normal.x * 0.01f, cur.pos.y + cur.normal.y * 0.01f, cur.pos.z + cur.normal.z * 0.01f);
         RayHit rh; RayInt ri;
         trace_ray<TRAV, Occ, false, true>(s, occ, o, rdir, st.max_steps, rh, ri);
-        c.fetches += ri.fetches; c.rays++;
+        if (VRT_COUNTS(TRAV)) c.fetches += ri.fetches;
+        c.rays++;
         if (rh.material == 0u) {                               // the chain ends in the sky: colorHit of a miss is skyColor(dir)
             const f3 col = sky_color(s, rh.dir);
             reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
@@ -772,7 +813,8 @@ __device__ f3 color_main_ray_packed(const GeomParams& P, const Occ occ, PixCtx& 
     }
     if (last < 0) {
         // frag:281-303 with lastIdx = -1: the bounces' secondary rays were traced for nothing -- the reference never traces them
-        c.fetches -= spec_fetches; c.rays -= spec_rays;
+        if (VRT_COUNTS(TRAV)) c.fetches -= spec_fetches;
+        c.rays -= spec_rays;
         last = 0;
     }
     // the way back: entry j (bounce j - 1) with the reflection gathered behind it, frag:300-303
@@ -1025,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_hit_colors(const GeomParams P, uint32_t
         RayHit h;
         h.material = material; h.pos = mk3(0.0f, 0.0f, 0.0f); h.dir = mk3(0.0f, 0.0f, 0.0f);
         h.normal = hit_normal(mask, sx, sy, sz); h.ncode = code;
-        PixCtx c; c.px = 0; c.py = 0; c.fetches = 0; c.rays = 0; c.pc = nullptr; c.have_noise = false;
+        PixCtx c; c.px = 0; c.py = 0; c.fetches = 0; c.rays = 0; c.pc = nullptr; c.have_noise = false; c.ldsw = 0u;
         OccT<false> occ; occ.o2 = nullptr; occ.o3 = nullptr;
         const f3 col = color_hit<VRT_TRAVERSAL_DF_FAST, OccT<false>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);
         c8 = (uint32_t)unorm8(col.x) | ((uint32_t)unorm8(col.y) << 8) | ((uint32_t)unorm8(col.z) << 16);
@@ -1236,8 +1278,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         f.hit_voxel[i * 3 + 2] = hit ? (int16_t)r.mz : (int16_t)0;
     }
     if (f.hit_mask) f.hit_mask[i] = hit ? (uint8_t)r.mask : (uint8_t)0;
-    if (f.steps_primary) f.steps_primary[i] = r.fetches;
-    if (f.steps_total) f.steps_total[i] = (P.st.flags & VRT_FLAG_DEBUG_PLANES) ? r.dbg0 : r.fetches;
+    if (VRT_COUNTS(TRAV) && f.steps_primary) f.steps_primary[i] = r.fetches;
+    if (VRT_COUNTS(TRAV) && f.steps_total) f.steps_total[i] = (P.st.flags & VRT_FLAG_DEBUG_PLANES) ? r.dbg0 : r.fetches;
     if (f.rays_total) f.rays_total[i] = (P.st.flags & VRT_FLAG_DEBUG_PLANES) ? r.dbg1 : 1u;
     if ((P.st.flags & 2u) && f.steps_total && f.rays_total) {             // wave start / end stamps, 10 ns units
         f.steps_total[i] = (uint32_t)t_begin;
@@ -1267,11 +1309,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         f3 col;
         if (hit) {
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame); c.have_noise = false;
+            c.ldsw = (uint32_t)(uintptr_t)(lds_u64_ptr)lds_occ + (uint32_t)wave * (uint32_t)VRT_AO_SLOT;   // (the hand-written loop's kernels are launched with a pool per wave)
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
                 if (MODE >= 5) col = color_main_ray_packed<TRAV, OccT<kLds>, (MODE == 5 ? 2 : (MODE == 6 ? 5 : VRT_MAX_BOUNCES))>(P, occ, c, h);
                 else col = color_main_ray<TRAV, OccT<kLds>, MODE != 4>(P, occ, c, h);
-                if (steps_total && !(P.st.flags & 3u)) steps_total[i] = r.fetches + c.fetches;
+                if (VRT_COUNTS(TRAV) && steps_total && !(P.st.flags & 3u)) steps_total[i] = r.fetches + c.fetches;
                 if (rays_total && !(P.st.flags & 3u)) rays_total[i] = 1u + c.rays;
             }
         } else {
@@ -1322,6 +1365,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     uint32_t mask = (rec.w >> 8) & 7u;
     int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;
     PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &P.slot[0].pc; c.have_noise = false;
+    c.ldsw = (uint32_t)(uintptr_t)(lds_u64_ptr)lds_occ + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (uint32_t)VRT_AO_SLOT;
     h.normal = hit_normal(mask, sx, sy, sz);
     {
         const bool general = (mask & 7u) == 0u || ((mask & 1u) && sx == 0) || ((mask & 2u) && sy == 0) || ((mask & 4u) && sz == 0);
@@ -1339,7 +1383,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
             reinterpret_cast<uchar4*>(f.color8_strips)[(size_t)yp * (size_t)P.W + (size_t)px] = c8;
         }
     }
-    if (f.steps_total) f.steps_total[i] += c.fetches;
+    if (VRT_COUNTS(TRAV) && f.steps_total) f.steps_total[i] += c.fetches;
     if (f.rays_total) f.rays_total[i] += c.rays;
 }
 
@@ -1442,6 +1486,8 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
     else if (p.xcd_turn) grid = dim3((unsigned)p.tiles_x * 8u * (unsigned)((p.tiles_y_local * p.n_frames + 7) / 8));
     dim3 block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
+    // (the hand-written loop's AO batches: one slot of waiting rays per wave, df_ao_batch_loop)
+    if ((TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT) && p.fused_shade != 1) lds = (size_t)(block.x / 64u) * (size_t)VRT_AO_SLOT;
     // (the product traversals with the tile map's form as a compile-time constant: block_to_tile)
     constexpr bool kProduct = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK;
     const int map = (kProduct && p.xcd_turn != 1) ? p.xcd_turn : -1;
@@ -1470,6 +1516,7 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
     // workgroups leave at once
     dim3 grid((unsigned)(((size_t)p.total_tiles * p.tile_w * p.tile_h + 255) / 256)), block(256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
+    if (TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT) lds = 4u * (size_t)VRT_AO_SLOT;
     hipLaunchKernelGGL((k_shade<TRAV, OCC_LDS>), grid, block, lds, s, p);
     return hipGetLastError();
 }
@@ -1498,7 +1545,8 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s)
 hipError_t launch_shade(const GeomParams& p, hipStream_t s)
 {
     int t = effective_traversal((int)p.st.traversal, p.fast_loop);
-    if (t == VRT_TRAVERSAL_DF_FAST || t == VRT_TRAVERSAL_DF_FAST_CNT) return launch_shade_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
+    if (t == VRT_TRAVERSAL_DF_FAST) return launch_shade_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
+    if (t == VRT_TRAVERSAL_DF_FAST_CNT) return launch_shade_t<VRT_TRAVERSAL_DF_FAST_CNT, false>(p, s);
     if (t == VRT_TRAVERSAL_BRICK) return launch_shade_t<VRT_TRAVERSAL_BRICK, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_shade_t<VRT_TRAVERSAL_DF, false>(p, s);

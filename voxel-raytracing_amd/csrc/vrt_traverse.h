@@ -79,6 +79,7 @@ struct VolumeView {
                                 // bits 32..63 the coarse clearance of the eight octants, four bits each (0 = occupied or border, else
                                 // min(15, bricks)) -- bgrid and bcoarse folded into one load instead of two dependent ones
     uint32_t        df_own;      // 1: AO rays through df_any_loop (development switch)
+    uint32_t        ao_batch;    // 1: the hand-written loop's kernels trace the AO rays of a wave from a pool in LDS every lane draws on (df_ao_pool_loop; context option "ao_batch")
     uint32_t        df_prefetch; // 1: the secondary rays' look-ups through trace_df_fast prefetch the neighbouring rows (development switch)
     uint32_t        df_thresh;   // 1: primary rays through df_prim_loop (long runs by threshold; launches that report no iteration counts)
     uint32_t        brick_open;  // 1: bit 7 of a coarse byte (no occupied brick is left in the box between this brick and the volume's
@@ -800,6 +801,10 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 #undef VRT_DF_COUNT
 }
 
+// an AO ray as df_ao_pool_loop takes it up, and the LDS bytes of a wave's pool (11 dwords x 64 columns) + its two rows of counters
+struct AoRay { float x, y, z, dx, dy, dz, gx, gy, gz; uint32_t idx0, voxoff; };
+#define VRT_AO_SLOT 3328
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- DF, hand-written look-up loop (primary rays of the primary-only kernel) ----------------------------------------------
 // Same march, same results as trace_df_impl<true, ., true>; what differs is what it costs to get from one look-up to the
@@ -1494,6 +1499,211 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
 #undef VRT_A_ITER
 }
 
+// ---- AO rays from a pool the whole wave draws on ---------------------------------------------------------------------------------
+// What an AO trace costs is its ROUNDS: every look-up is a gather the next run depends on, and a wave goes round until its
+// neediest lane is done.  The AO rays of a wave point every way and need very different numbers of looks -- on the Mandelbulb 7.8
+// on average and 30 for the neediest of 64 (a quarter of the lanes of an AO look-up are live: tools/exp_r4_ao_util.py) -- and the
+// long rays belong to the same pixels sample after sample (a pixel in a crevice stays in its crevice): letting a lane go on to
+// ITS OWN next ray the moment it is done (first attempt of round 4) measured no gain at all.  So the rays are not the lanes':
+// every lane writes the ray of its pixel's next AO sample into a pool in LDS (11 dwords: the state trace_df_fast sets up), and a
+// lane that is done takes the NEXT RAY OF THE POOL, whoever's it is -- the slot is the wave's counter + the lane's rank among the
+// lanes asking in this round (v_mbcnt: no atomic, the wave runs in lock step) -- and reports what it finds to the owner's counter
+// in LDS.  When the pool is empty and a lane rests, the loop returns, the lanes write their next sample's rays and the loop goes
+// on where it was: the work of a pixel's four AO rays is spread over the wave, and a wave takes about
+// max(all looks / lanes, longest single ray) rounds instead of the sum of four maxima.
+// Otherwise df_any_loop: every lane spends its ray's own clearance (at most VRT_OWN_CAP iterations per look), the same fp32
+// additions per ray in the same order, the iteration count of a ray its own -- which ray a lane works on changes no result.
+// A ray that never enters the volume is handed over with zero deltas and an index whose byte is 0 (the first byte of a field:
+// its border): it ends at its first look, as a miss, like any other ray ends.
+// LDS of a wave (VRT_AO_SLOT bytes at ldsw): the pool, dword q of the ray in column k at q * 256 + k * 4 (x y z dx dy dz gx gy gz idx0
+// voxoff); at 2816 one counter per column: rays of that column's pixel that found a solid voxel; at 3072 (CNT) what the count planes
+// report for them.  Column = rank of the pixel's lane among the lanes the AO phase runs under.
+template <bool CNT>
+__device__ __forceinline__ void df_ao_pool_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
+                                                uint32_t ldsw, uint32_t ldsh, uint32_t count, uint32_t more, uint32_t& next,
+                                                float& x, float& y, float& z, float& dx, float& dy, float& dz,
+                                                float& gx, float& gy, float& gz, float& cx, float& cy, float& cz,
+                                                uint32_t& idx0, uint32_t& voxoff, uint32_t& state, uint32_t& owner,
+                                                uint32_t marched, uint32_t& looks)
+{
+    // vectors of the block: v48..v50 temporaries, v52 the byte read (0xFD: the ray ended in this round, 0xFE: a ray just taken up,
+    // 0xFF: the lane rests), v53 its index, v54 = i (iterations of the lane's current ray), v55 = iterations it may take before it
+    // looks again, v56 = voxel id on its way, v57 = LDS address of the counter of the ray that id belongs to; scalars: s61 temporary,
+    // s62 = 0x80, s63 = 0xFF, s[64:65] lanes with some left, s[66:67] / s[70:71] saved EXEC, s[68:69] EXEC on entry
+#define VRT_A_ITER                                               \
+        "v_cmp_lt_u32_e32 vcc, 0, v55\n\t"                        \
+        "s_cbranch_vccz 30f\n\t"                                  \
+        "s_mov_b64 s[64:65], vcc\n\t"                             \
+        "s_mov_b64 exec, vcc\n\t"                                 \
+        "v_subrev_u32 v55, 1, v55\n\t"                            \
+        "v_min3_u32 v48, %[x], %[y], %[z]\n\t"                    \
+        "v_cmpx_eq_u32 v48, %[x]\n\t"                             \
+        "v_add_f32 %[x], %[x], %[dx]\n\t"                         \
+        "s_mov_b64 exec, s[64:65]\n\t"                            \
+        "v_cmpx_eq_u32 v48, %[y]\n\t"                             \
+        "v_add_f32 %[y], %[y], %[dy]\n\t"                         \
+        "s_mov_b64 exec, s[64:65]\n\t"                            \
+        "v_cmpx_eq_u32 v48, %[z]\n\t"                             \
+        "v_add_f32 %[z], %[z], %[dz]\n\t"                         \
+        "s_mov_b64 exec, s[68:69]\n\t"
+    // the ids asked for when rays read 0 have arrived: a ray that found a solid voxel counts for its owner (L: a label of its own)
+#define VRT_Q_COUNT_ID(L, CNT_SOLID)                             \
+        "v_cmp_ne_u32_e32 vcc, 0, v56\n\t"                        \
+        "s_cbranch_vccz " L "f\n\t"                               \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t"                    \
+        "v_mov_b32 v48, 1\n\t"                                    \
+        "ds_add_u32 v57, v48\n\t"                                 \
+        CNT_SOLID                                                 \
+        "s_mov_b64 exec, s[66:67]\n\t"                            \
+        L ":\n\t"                                                 \
+        "v_mov_b32 v56, 0\n\t"
+#define VRT_Q_LOOP(CNT_LOOK, CNT_FIND, CNT_MISS, CNT_SOLID, CNT_OPND) \
+    asm volatile( \
+        ".p2align 6\n\t" \
+        "s_movk_i32 s63, 0xff\n\t" \
+        "s_movk_i32 s62, 0x80\n\t" \
+        "s_mov_b64 s[68:69], exec\n\t" \
+        "v_and_b32 v52, 0xff, %[st]\n\t" /* (between calls: the byte in bits 0..7, the iterations of the lane's ray above) */ \
+        "v_lshrrev_b32 v54, 8, %[st]\n\t" \
+        "v_mov_b32 v53, %[idx0]\n\t" \
+        "v_mov_b32 v56, 0\n\t" \
+        "s_branch 125f\n\t" /* (the lanes that rest take their rays first) */ \
+        "10:\n\t" /* ---- every lane's byte is here, and the ids asked for in the round before ---- */ \
+        CNT_LOOK \
+        "s_waitcnt vmcnt(0)\n\t" \
+        VRT_Q_COUNT_ID("101", CNT_SOLID) \
+        "v_cmp_eq_u32_e32 vcc, 0, v52\n\t" /* solid, border or open cell: the ray ends here; the voxel id says which */ \
+        "s_cbranch_vccz 12f\n\t" \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" \
+        "v_add_u32 v48, v53, %[voxoff]\n\t" \
+        "global_load_ubyte v56, v48, %[base]\n\t" \
+        "v_lshl_add_u32 v57, %[own], 2, %[ldsh]\n\t" /* the counter of the pixel this ray belongs to */ \
+        CNT_FIND \
+        "v_mov_b32 v52, 0xfd\n\t" \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "12:\n\t" \
+        "v_cmp_gt_u32_e64 s[64:65], s62, v52\n\t" /* lanes with a clearance (1 .. 127) ... */ \
+        "v_sub_u32 v48, %[maxs], v54\n\t" /* ... what is left of their ray's budget ... */ \
+        "s_nop 0\n\t" \
+        "v_cmp_le_u32_e32 vcc, v48, v52\n\t" /* ... and whether the clearance covers it: a miss at the budget */ \
+        "s_and_b64 vcc, vcc, s[64:65]\n\t" \
+        "s_cbranch_vccz 125f\n\t" \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" \
+        CNT_MISS \
+        "v_mov_b32 v52, 0xfd\n\t" \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "125:\n\t" /* ---- lanes whose ray ended in this round, and lanes that rest: the next rays of the pool ---- */ \
+        "v_cmp_eq_u32_e32 vcc, 0xfd, v52\n\t" \
+        "v_cmp_eq_u32_e64 s[64:65], s63, v52\n\t" \
+        "s_nop 1\n\t" \
+        "s_or_b64 vcc, vcc, s[64:65]\n\t" \
+        "s_cbranch_vccz 13f\n\t" \
+        "s_mov_b64 s[70:71], vcc\n\t" \
+        "s_and_saveexec_b64 s[66:67], vcc\n\t" \
+        "v_mbcnt_lo_u32_b32 v48, s70, 0\n\t" \
+        "v_mbcnt_hi_u32_b32 v48, s71, v48\n\t" /* the lane's rank among those asking ... */ \
+        "v_add_u32 v48, %[nx], v48\n\t" /* ... + the rays taken so far = its ray's column */ \
+        "s_bcnt1_i32_b64 s61, s[70:71]\n\t" \
+        "v_cmp_gt_u32_e32 vcc, %[cnt], v48\n\t" /* the pool has that many */ \
+        "s_add_u32 %[nx], %[nx], s61\n\t" \
+        "s_min_u32 %[nx], %[nx], %[cnt]\n\t" \
+        "s_and_saveexec_b64 s[70:71], vcc\n\t" /* EXEC = asking and served; s[70:71] = asking */ \
+        "s_cbranch_execz 126f\n\t" \
+        "v_lshl_add_u32 v49, v48, 2, %[ldsw]\n\t" \
+        "v_mov_b32 %[own], v48\n\t" \
+        "ds_read_b32 %[x], v49\n\t" \
+        "ds_read_b32 %[y], v49 offset:256\n\t" \
+        "ds_read_b32 %[z], v49 offset:512\n\t" \
+        "ds_read_b32 %[dx], v49 offset:768\n\t" \
+        "ds_read_b32 %[dy], v49 offset:1024\n\t" \
+        "ds_read_b32 %[dz], v49 offset:1280\n\t" \
+        "ds_read_b32 %[gx], v49 offset:1536\n\t" \
+        "ds_read_b32 %[gy], v49 offset:1792\n\t" \
+        "ds_read_b32 %[gz], v49 offset:2048\n\t" \
+        "ds_read_b32 %[idx0], v49 offset:2304\n\t" \
+        "ds_read_b32 %[voxoff], v49 offset:2560\n\t" \
+        "v_mov_b32 v54, 0\n\t" \
+        "v_mov_b32 v52, 0xfe\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_mul_legacy_f32 %[cx], %[x], %[gx]\n\t" /* c = -(side0 * g): where the ray stands is rint(side * g + c) steps from its start */ \
+        "v_mul_legacy_f32 %[cy], %[y], %[gy]\n\t" \
+        "v_mul_legacy_f32 %[cz], %[z], %[gz]\n\t" \
+        "v_xor_b32 %[cx], 0x80000000, %[cx]\n\t" \
+        "v_xor_b32 %[cy], 0x80000000, %[cy]\n\t" \
+        "v_xor_b32 %[cz], 0x80000000, %[cz]\n\t" \
+        "126:\n\t" \
+        "s_andn2_b64 exec, s[70:71], vcc\n\t" /* asking and not served: the lane rests (zero deltas, the 0xFF byte) */ \
+        "s_cbranch_execz 127f\n\t" \
+        "v_mov_b32 %[dx], 0\n\t" \
+        "v_mov_b32 %[dy], 0\n\t" \
+        "v_mov_b32 %[dz], 0\n\t" \
+        "v_mov_b32 %[gx], 0\n\t" \
+        "v_mov_b32 %[gy], 0\n\t" \
+        "v_mov_b32 %[gz], 0\n\t" \
+        "v_mov_b32 %[cx], 0\n\t" \
+        "v_mov_b32 %[cy], 0\n\t" \
+        "v_mov_b32 %[cz], 0\n\t" \
+        "v_mov_b32 %[idx0], %[sent]\n\t" \
+        "v_mov_b32 v53, %[sent]\n\t" \
+        "v_mov_b32 v52, s63\n\t" \
+        "127:\n\t" \
+        "s_mov_b64 exec, s[66:67]\n\t" \
+        "s_cmp_lt_u32 %[nx], %[cnt]\n\t" /* the pool is empty, the pixels have more samples, and a lane rests: back to have it refilled */ \
+        "s_cbranch_scc1 13f\n\t" \
+        "s_cmp_eq_u32 %[more], 0\n\t" \
+        "s_cbranch_scc1 13f\n\t" \
+        "v_cmp_eq_u32_e32 vcc, s63, v52\n\t" \
+        "s_cbranch_vccnz 40f\n\t" \
+        "13:\n\t" \
+        "v_cmp_ne_u32_e32 vcc, s63, v52\n\t" /* who is live now */ \
+        "s_cbranch_vccz 40f\n\t" /* nobody: done, or the pool wants refilling */ \
+        "v_cmp_gt_u32_e32 vcc, s62, v52\n\t" /* iterations a lane may take: its clearance (none for a ray just taken up, or a resting lane) */ \
+        "v_cndmask_b32_e32 v55, 0, v52, vcc\n\t" \
+        "v_min_u32 v55, " VRT_STR(VRT_OWN_CAP) ", v55\n\t" /* ... but no more than a few: the others wait for the longest */ \
+        "v_add_u32 v54, v54, v55\n\t" /* it will take them all before the next look */ \
+        "20:\n\t" /* ---- iterations for the lanes that have some left (four per trip) ---- */ \
+        VRT_A_ITER VRT_A_ITER VRT_A_ITER VRT_A_ITER \
+        "s_branch 20b\n\t" \
+        "30:\n\t" /* ---- where is every lane now?  request its next byte ---- */ \
+        "v_mul_legacy_f32 v48, %[x], %[gx]\n\t" \
+        "v_mul_legacy_f32 v49, %[y], %[gy]\n\t" \
+        "v_mul_legacy_f32 v50, %[z], %[gz]\n\t" \
+        "v_add_f32 v48, v48, %[cx]\n\t" \
+        "v_add_f32 v49, v49, %[cy]\n\t" \
+        "v_add_f32 v50, v50, %[cz]\n\t" \
+        "v_cvt_rpi_i32_f32 v48, v48\n\t" \
+        "v_cvt_rpi_i32_f32 v49, v49\n\t" \
+        "v_cvt_rpi_i32_f32 v50, v50\n\t" \
+        "v_mad_i32_i24 v48, v49, %[pw], v48\n\t" \
+        "v_mad_i32_i24 v48, v50, %[pwh], v48\n\t" \
+        "v_add_u32 v53, %[idx0], v48\n\t" \
+        "global_load_ubyte v52, v53, %[base]\n\t" \
+        "s_branch 10b\n\t" \
+        "40:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        VRT_Q_COUNT_ID("401", CNT_SOLID) \
+        "v_lshl_or_b32 %[st], v54, 8, v52\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "s_mov_b64 exec, s[68:69]\n\t" \
+        : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [dx] "+v"(dx), [dy] "+v"(dy), [dz] "+v"(dz), \
+          [gx] "+v"(gx), [gy] "+v"(gy), [gz] "+v"(gz), [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz), \
+          [idx0] "+v"(idx0), [voxoff] "+v"(voxoff), [st] "+v"(state), [own] "+v"(owner), [nx] "+s"(next) CNT_OPND \
+        : [base] "s"(base), [maxs] "s"(maxSteps), [pw] "s"(pw), [pwh] "s"(pwh), [sent] "s"(sentinel), [mar] "s"(marched), \
+          [ldsw] "s"(ldsw), [ldsh] "s"(ldsh), [cnt] "s"(count), [more] "s"(more) \
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v52", "v53", "v54", "v55", "v56", "v57", \
+          "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71")
+    if (CNT) {
+        VRT_Q_LOOP(VRT_CNT_LOOK,
+                   "v_add_u32 %[lk], 1, %[lk]\n\t" "ds_add_u32 v57, v54 offset:256\n\t",
+                   "v_lshl_add_u32 v49, %[own], 2, %[ldsh]\n\t" "v_mov_b32 v50, %[maxs]\n\t" "s_cmp_eq_u32 %[mar], 0\n\t" "s_cbranch_scc1 141f\n\t" "v_mov_b32 v50, v54\n\t" "141:\n\t" "ds_add_u32 v49, v50 offset:256\n\t",
+                   "ds_add_u32 v57, v48 offset:256\n\t",
+                   VRT_CNT_OPND);
+    } else {
+        VRT_Q_LOOP(VRT_CNT_NONE, VRT_CNT_NONE, VRT_CNT_NONE, VRT_CNT_NONE, VRT_CNT_NOOP);
+    }
+#undef VRT_A_ITER
+}
+
 // PF: the look-ups ask for the two neighbouring rows as well (secondary rays: VRT_F_PREFETCH)
 // OWN: every lane spends its own clearance (df_any_loop; any-hit rays)
 // CNT: the counting twins of the loops (VRT_TRAVERSAL_DF_FAST_CNT): r.fetches = what the march DID for this ray -- the iterations it took
@@ -1581,10 +1791,78 @@ __device__ __forceinline__ void trace_df_fast(const VolumeView& v, f3 start, f3 
     finish(s, material, lmask, reported, r);
     (void)stats; (void)gx0; (void)gy0; (void)gz0; (void)cx0; (void)cy0; (void)cz0;
 }
+
+// ---- AO rays through the wave's pool (df_ao_pool_loop) ---------------------------------------------------------------------------
+// trace_df_fast's set-up of one ray (frag:109-144 + the index into its octant's clearance field)
+__device__ __forceinline__ void ao_ray_setup(const VolumeView& v, f3 start, f3 dir, AoRay& a)
+{
+    DdaState s;
+    dda_entry(v, start, dir, s);
+    dda_rest(dir, s);
+    const bool done0 = oob(v, s.mx, s.my, s.mz);
+    const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
+    const uint32_t stride = (uint32_t)v.df_stride;
+    const int pw = v.W + 2, pwh = pw * (v.H + 2);
+    const uint32_t bias = (uint32_t)pwh, octoff = bias + oct * stride;
+    const float kInf = u2f(0x7F800000u);
+    a.x = s.sdx; a.y = s.sdy; a.z = s.sdz;
+    a.dx = done0 ? 0.0f : s.dx; a.dy = done0 ? 0.0f : s.dy; a.dz = done0 ? 0.0f : s.dz;
+    a.gx = (!done0 && s.dx < kInf) ? dir.x : 0.0f; a.gy = (!done0 && s.dy < kInf) ? dir.y : 0.0f; a.gz = (!done0 && s.dz < kInf) ? dir.z : 0.0f;
+    // a ray that never enters the volume: the first byte of its field -- the border, 0 -- ends it at its first look, as a miss
+    a.idx0 = done0 ? octoff : octoff + (uint32_t)df_index(v, s.mx, s.my, s.mz);
+    a.voxoff = 8u * stride - (octoff - bias);
+}
+
+// a ray into column `col` of the wave's pool (ldsw: the byte address of the wave's LDS)
+__device__ __forceinline__ void ao_ray_store(uint32_t ldsw, uint32_t col, const AoRay& a)
+{
+    __attribute__((address_space(3))) uint32_t* p = (__attribute__((address_space(3))) uint32_t*)(ldsw + col * 4u);
+    p[0 * 64] = f2u(a.x); p[1 * 64] = f2u(a.y); p[2 * 64] = f2u(a.z);
+    p[3 * 64] = f2u(a.dx); p[4 * 64] = f2u(a.dy); p[5 * 64] = f2u(a.dz);
+    p[6 * 64] = f2u(a.gx); p[7 * 64] = f2u(a.gy); p[8 * 64] = f2u(a.gz);
+    p[9 * 64] = a.idx0; p[10 * 64] = a.voxoff;
+}
+
+// What a lane of the pool loop carries from one call to the next: the ray it is on (or the resting state it starts in)
+struct AoLane { float x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz; uint32_t idx0, voxoff, state, owner; };
+__device__ __forceinline__ void ao_lane_rest(const VolumeView& v, AoLane& l)
+{
+    const uint32_t stride = (uint32_t)v.df_stride;
+    const int pw = v.W + 2, pwh = pw * (v.H + 2);
+    l.x = l.y = l.z = l.dx = l.dy = l.dz = l.gx = l.gy = l.gz = l.cx = l.cy = l.cz = 0.0f;
+    l.idx0 = (uint32_t)pwh + 9u * stride; l.voxoff = 0u; l.state = 0xFFu; l.owner = 0u;
+}
+
+// One call of the pool loop: `count` rays wait in the pool, `next` of them are taken (in / out), `more`: the pixels have further
+// samples, so come back when the pool is empty and a lane rests.  looks (CNT): clearance bytes + ids this LANE asked for.
+template <bool CNT>
+__device__ __forceinline__ void trace_ao_pool(const VolumeView& v, AoLane& l, uint32_t ldsw, uint32_t count, uint32_t more, uint32_t& next,
+                                              uint32_t maxSteps, uint32_t& looks)
+{
+    const uint32_t stride = (uint32_t)v.df_stride;
+    const int pw = v.W + 2, pwh = pw * (v.H + 2);
+    const uint32_t bias = (uint32_t)pwh, sentinel = bias + 9u * stride;
+    const uint64_t b64 = (uint64_t)v.df - (uint64_t)bias;
+    const uint8_t* base = (const uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
+                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));
+    const uint32_t lw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ldsw);
+    uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    df_ao_pool_loop<CNT>(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), lw, lw + 2816u, (uint32_t)__builtin_amdgcn_readfirstlane((int)count),
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)more), nx,
+                         l.x, l.y, l.z, l.dx, l.dy, l.dz, l.gx, l.gy, l.gz, l.cx, l.cy, l.cz, l.idx0, l.voxoff, l.state, l.owner,
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)v.count_marched), looks);
+    next = nx;
+}
 #else
 // host pass of a .hip file / the host build of the unit tests: parsed, never run (the loop is gfx950 assembly)
 template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false, bool CNT = false>
 VRT_HD void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
+VRT_HD void ao_ray_setup(const VolumeView&, f3, f3, AoRay&) {}
+VRT_HD void ao_ray_store(uint32_t, uint32_t, const AoRay&) {}
+struct AoLane { float x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz; uint32_t idx0, voxoff, state, owner; };
+VRT_HD void ao_lane_rest(const VolumeView&, AoLane&) {}
+template <bool CNT> VRT_HD void trace_ao_pool(const VolumeView&, AoLane&, uint32_t, uint32_t, uint32_t, uint32_t&, uint32_t, uint32_t&) {}
 #endif
 
 template <class STATS, bool AHEAD = false>
