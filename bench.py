@@ -643,7 +643,14 @@ def main():
                 usable = len(os.sched_getaffinity(0))
             except Exception:
                 usable = os.cpu_count() or 1
-            ncores = max(1, min(usable, 128))
+            quota = None                                       # (a cgroup CPU quota below the affinity mask: more threads than that only contend)
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    quota = max(1, int(-(-int(q) // int(per))))
+            except Exception:
+                pass
+            ncores = max(1, min(usable, quota or usable, 256))
             # a bounded sample of the same workload: every (F / 8)-th frame of the step, i.e. 8 full frames spread over the
             # camera path (about 10 CPU-seconds at 1080p: 0.6 s of wall time on 16 threads)
             sample = list(range(0, F, max(1, F // 8)))[:8]
@@ -655,7 +662,7 @@ def main():
                     same = bool((exp["hit_id"] == hit0).all()) and int(exp["steps_primary"].sum()) == S_frame
                     same_color = bool((exp["color8"] == color0).all())
             cdt = time.perf_counter() - c0
-            cpu = {"value": round(len(sample) * W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "hardware_threads": os.cpu_count(), "usable_threads": usable, "kind": "port",
+            cpu = {"value": round(len(sample) * W * H / cdt / 1e6, 3), "unit": "Mrays/s", "cores": ncores, "hardware_threads": os.cpu_count(), "usable_threads": usable, "cgroup_cpu_quota": quota, "kind": "port",
                    "sample": f"{len(sample)} full {W}x{H} frames of the same workload (every {max(1, F // 8)}th pose of the step), scalar C oracle, "
                              f"rows interleaved over {ncores} threads, {cdt:.2f} s",
                    "hit_ids_match_gpu": same, "color8_matches_gpu": same_color,

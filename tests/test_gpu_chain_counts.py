@@ -82,7 +82,7 @@ def test_packed_chain_on_bricks(vrt, oracle, engine):
     st.traceSettings.maxReflections = 4
     push = camera_push(vrt, (n, n, n), res, pos=(50.3, 40.2, 55.4), yaw=225.0, pitch=-25.0, frame=3)
     exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=ALL, nthreads=8)
-    for pk in (1, 0):
+    for pk in (2, 0):                                          # (brick scenes keep the stack of hits unless the option says 2)
         got = _render(vrt, engine, sb, st, push, ALL, packed_bounces=pk)
         assert not compare_planes(got, exp, ALL), ("brick scene, packed" if pk else "brick scene, stack", compare_planes(got, exp, ALL))
     sb.destroy()
@@ -131,3 +131,30 @@ def test_counting_twins(vrt, oracle, engine):
             if not ties:
                 assert lk.sum() < b.sum(), (name, pos, "the clearance runs are what keeps the march from asking per iteration")
     sc.destroy()
+
+
+def test_counting_on_bricks(vrt, oracle, engine):
+    """brick scenes: the march that is timed (brick_march_thresh) counts its own steps and bytes under the flags; on rays that hit,
+    steps = the counting loop's iterations (no ties from this camera)"""
+    vol = vrt.synthetic.treehouse(64, seed=4)
+    pal = metallic_palette(vrt)
+    sky, noise = vrt.synthetic.sky_gradient(64, 32), vrt.synthetic.blue_noise_standin(64)
+    grid, pool = vrt.synthetic.bricks_from_dense(vol)
+    sb = vrt.VoxelScene.from_bricks(engine, grid, pool, pal, sky=sky, noise=noise)
+    osn = oracle.OracleScene(vol, pal, sky=sky, noise=noise)
+    res = (96, 64)
+    CNT = ["steps_primary", "steps_total", "rays_total"]
+    st = vrt.VoxelRenderSettings.primary_only(res)
+    push = camera_push(vrt, (64, 64, 64), res, pos=(32.37, 30.21, -50.0), frame=2)
+    exp = oracle.render(osn, push, oracle.params_from(st.to_c()), planes=GB + ["hit_id"] + CNT, nthreads=8)
+    twin = _render(vrt, engine, sb, st, push, GB + ["hit_id"] + CNT, flags=16)
+    merged = _render(vrt, engine, sb, st, push, GB + ["hit_id"] + CNT, flags=16, thresh_runs=0)
+    looks = _render(vrt, engine, sb, st, push, GB + ["hit_id"] + CNT, flags=16 | 32)
+    for got in (twin, merged, looks):
+        assert not compare_planes(got, exp, GB + ["hit_id"])
+    hit = twin["hit_id"] != 0
+    assert hit.any() and (twin["steps_primary"][hit] == merged["steps_primary"][hit]).all()
+    assert (twin["steps_primary"][hit] == exp["steps_primary"][hit]).all(), "a ray that hits takes the reference's iterations"
+    lk = looks["steps_primary"].astype(np.int64)
+    assert (lk[hit] >= 10).all() and (lk[hit] % 1 == 0).all()         # at least one brick word + fine byte + id
+    sb.destroy()

@@ -21,10 +21,14 @@ BUDGET = {
     "k_primaryILi7ELb0ELi1ELb0ELi2EE": ("K1 primary-only, look-up loop, 8 frames in the kernel arguments (XCD regions)", 64, 80, 0),
     "k_primaryILi7ELb0ELi1ELb1ELi0EE": ("K1 primary-only, look-up loop, slots in the table, rows dealt to the XCDs (the bench line's kernel)", 64, 80, 0),
     "k_primaryILi7ELb0ELi1ELb1ELi2EE": ("K1 primary-only, look-up loop, slots in the table, XCD regions", 64, 80, 0),
-    "k_primaryILi7ELb0ELi4ELb0ELi0EE": ("megakernel without its bounce loop, one frame per launch", 64, 80, 0),
+    # (round 4: with the AO rays' pool the kernel needs 65 VGPRs, i.e. 7 waves per SIMD; forced into 64 it spills 12 B per lane and runs
+    # the same 124-128 us on the reference defaults: tools/exp_r4_breakdown.py, libvrt_hip_m8.so -- no scratch is the invariant kept)
+    "k_primaryILi7ELb0ELi4ELb0ELi0EE": ("megakernel without its bounce loop, one frame per launch", 72, 80, 0),
     "k_primaryILi7ELb0ELi4ELb1ELi2EE": ("megakernel without its bounce loop, table", 72, 96, 0),
-    "k_primaryILi7ELb0ELi2ELb0ELi0EE": ("megakernel, one frame per launch (7 waves per SIMD by design)", 72, 96, 512),
-    "k_primaryILi7ELb0ELi2ELb1ELi2EE": ("megakernel, table", 72, 96, 512),
+    "k_primaryILi7ELb0ELi2ELb0ELi0EE": ("megakernel with the stack of hits (context option packed_bounces = 0), one frame per launch", 72, 96, 512),
+    "k_primaryILi7ELb0ELi2ELb1ELi2EE": ("megakernel with the stack of hits, table", 72, 96, 512),
+    "k_primaryILi7ELb0ELi5ELb0ELi0EE": ("megakernel, bounce chain as one word per hit, <= 2 bounces (BASELINE configs[3]), one frame per launch", 72, 96, 160),
+    "k_primaryILi7ELb0ELi6ELb0ELi0EE": ("megakernel, bounce chain as one word per hit, <= 5 bounces (the reference's defaults), one frame per launch", 72, 96, 192),
     "k_primaryILi6ELb0ELi2ELb0ELi0EE": ("megakernel over bricks (config 5), one frame per launch", 80, 96, 576),
     "k_denoise_ldsILb0ELb0ELb0ELb1EE": ("K3 weighted pass, exact, packed", 128, 96, 0),
     # (the verified pass: four workgroups of four waves per compute unit, i.e. at most 128 VGPRs; 96 leaves it five)

@@ -1007,7 +1007,9 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
     p.fused_shade = (st->ao_samples == 0 && st->shadows == 0 && (st->max_bounces == 0 || !s->metallic_voxels)) ? 1 : ((st->flags & VRT_FLAG_SPLIT_KERNELS) ? 0 : 2);
     p.no_bounce = ((st->max_bounces == 0 || !s->metallic_voxels) && c->opt.no_bounce_kernel) ? 1 : 0;
     p.sc.vol.ao_batch = (c->opt.ao_batch && p.sc.vol.df_own) ? 1u : 0u;
-    p.packed_chain = (c->opt.packed_bounces && st->ao_samples <= 0xFFFFu) ? 1 : 0;     // (16 bits of a chain word count the AO rays that hit)
+    // (16 bits of a chain word count the AO rays that hit; brick scenes keep the stack of hits: the packed chain measured 6 % slower there --
+    // 3.46 against 3.25 ms on config 5 -- and 1 % faster on the Mandelbulb; context option packed_bounces = 2 forces it everywhere)
+    p.packed_chain = (c->opt.packed_bounces && st->ao_samples <= 0xFFFFu && (!s->bricks || c->opt.packed_bounces >= 2)) ? 1 : 0;
     // default traversal and budgets the recovery of positions from sideDist is exact for: the hand-written look-up loop
     // (vrt_traverse.h trace_df_fast) for every ray of the frame
     {
@@ -1018,12 +1020,13 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
                   !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && (!sec || st->ao_samples == 0 || (st->ao_steps >= 1 && st->ao_steps <= 1024));
         for (int f = 0; f < n && ok; f++) ok = frames[f].hit_voxel == nullptr;      // the fast loop keeps no mapPos: no hit_voxel plane
         p.fast_loop = ok ? ((counts || (st->flags & VRT_FLAG_MARCHED_COUNTS)) ? 2 : 1) : 0;      // (2: the loops' counting twins -- every launch that fills iteration-count planes)
+        if (s->bricks && (counts || (st->flags & (VRT_FLAG_MARCHED_COUNTS | VRT_FLAG_DEBUG_PLANES | 2u)))) p.fast_loop = 2;      // (bricks: the march with its counters)
         // ... and the primary rays' long runs by threshold (df_prim_loop): launches that report no iteration counts (the loop keeps
         // none), axis step counts the position recovery is exact for, a budget worth not counting
         const int dmax = s->d.vol.W > s->d.vol.H ? (s->d.vol.W > s->d.vol.D ? s->d.vol.W : s->d.vol.D) : (s->d.vol.H > s->d.vol.D ? s->d.vol.H : s->d.vol.D);
         p.sc.vol.df_thresh = (ok && c->opt.thresh_runs && !counts && dmax <= 1022 && st->max_steps >= 32) ? 1u : 0u;
         // (brick scenes: the generic loop's form of the same, brick_march_thresh; its positions come from per-run differences)
-        if (s->bricks) p.sc.vol.df_thresh = (c->opt.thresh_runs && !counts && !(st->flags & (VRT_FLAG_MARCHED_COUNTS | VRT_FLAG_DEBUG_PLANES | 2u)) && st->max_steps >= 32) ? 1u : 0u;
+        if (s->bricks) p.sc.vol.df_thresh = (c->opt.thresh_runs && !counts && !(st->flags & (VRT_FLAG_DEBUG_PLANES | 2u)) && st->max_steps >= 32) ? 1u : 0u;
     }
     // the sky texel of waves that cannot hit anything by vrt_sky.h: launches whose frames hold the reference's targets only
     // (a diagnostic plane wants values the short path does not make), pixel offsets that fit 32 bits, a sky the bound admits

@@ -423,7 +423,7 @@ __device__ __forceinline__ float decode_snorm8(int32_t c)
 // every AO sample and every bounce of the pixel)
 // (kernels of VRT_TRAVERSAL_DF_FAST never fill iteration-count planes -- vrt_api.hip sends every launch that has them to the counting twins,
 // VRT_TRAVERSAL_DF_FAST_CNT -- so for them `fetches` is dead and the compiler drops it: VRT_COUNTS(TRAV))
-#define VRT_COUNTS(TRAV) ((TRAV) != VRT_TRAVERSAL_DF_FAST)
+#define VRT_COUNTS(TRAV) ((TRAV) != VRT_TRAVERSAL_DF_FAST && (TRAV) != VRT_TRAVERSAL_BRICK)
 struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; f3 noise; bool have_noise;
                 uint32_t ldsw; };    // ldsw: byte address of the wave's VRT_AO_SLOT bytes of LDS (df_ao_pool_loop): kernels that trace AO rays through the hand-written loop
 
@@ -1098,8 +1098,11 @@ __device__ __forceinline__ void store_color(const vrt_frame& f, f3 col, size_t i
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
+#ifndef VRT_MODE4_WAVES
+#define VRT_MODE4_WAVES 7     // (development: 8 forces the megakernel without its bounce loop into 64 VGPRs, at the price of 12 B of scratch per lane)
+#endif
 template <int TRAV, bool OCC_LDS, int MODE, bool TABLE, int MAP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_primary(const GeomParams P)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((MODE == 4 && TRAV == VRT_TRAVERSAL_DF_FAST) ? VRT_MODE4_WAVES : 7), 8))) void k_primary(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     // the tile map arrives with one 64-byte scalar load (and one wait) before anything depends on it
@@ -1489,12 +1492,13 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
     // (the hand-written loop's AO batches: one slot of waiting rays per wave, df_ao_batch_loop)
     if ((TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT) && p.fused_shade != 1) lds = (size_t)(block.x / 64u) * (size_t)VRT_AO_SLOT;
     // (the product traversals with the tile map's form as a compile-time constant: block_to_tile)
-    constexpr bool kProduct = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK;
-    const int map = (kProduct && p.xcd_turn != 1) ? p.xcd_turn : -1;
+    constexpr bool kProduct = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK || TRAV == VRT_TRAVERSAL_BRICK_CNT;
+    constexpr bool kCount = TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK_CNT;      // (counting launches: the general tile map only -- fewer kernels to build)
+    const int map = (kProduct && !kCount && p.xcd_turn != 1) ? p.xcd_turn : -1;
 #define VRT_LAUNCH_K1(MODE_, TABLE_)                                                                                           \
     do {                                                                                                                       \
-        if (kProduct && map == 0)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, kProduct ? 0 : -1>), grid, block, lds, s, p); \
-        else if (kProduct && map == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, kProduct ? 2 : -1>), grid, block, lds, s, p); \
+        if (kProduct && !kCount && map == 0)      hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, (kProduct && !kCount) ? 0 : -1>), grid, block, lds, s, p); \
+        else if (kProduct && !kCount && map == 2) hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, (kProduct && !kCount) ? 2 : -1>), grid, block, lds, s, p); \
         else                           hipLaunchKernelGGL((k_primary<TRAV, OCC_LDS, MODE_, TABLE_, -1>), grid, block, lds, s, p);    \
     } while (0)
     if (p.table) {               // the split form renders one frame per launch and never gets here
@@ -1523,7 +1527,7 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
 
 static int effective_traversal(int t, int fast_loop)
 {
-    if (t == VRT_TRAVERSAL_BRICK) return t;
+    if (t == VRT_TRAVERSAL_BRICK) return fast_loop == 2 ? VRT_TRAVERSAL_BRICK_CNT : t;
     if (fast_loop == 2 && (t == VRT_TRAVERSAL_AUTO || t == VRT_TRAVERSAL_DF)) return VRT_TRAVERSAL_DF_FAST_CNT;     // the loops' counting twins
     if (t == VRT_TRAVERSAL_DENSE || t == VRT_TRAVERSAL_BITMASK || t == VRT_TRAVERSAL_JUMP || t == VRT_TRAVERSAL_DFJ) return t;
     return fast_loop ? VRT_TRAVERSAL_DF_FAST : VRT_TRAVERSAL_DF;        // AUTO / DF
@@ -1535,6 +1539,7 @@ hipError_t launch_primary(const GeomParams& p, hipStream_t s)
     if (t == VRT_TRAVERSAL_DF_FAST) return launch_primary_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
     if (t == VRT_TRAVERSAL_DF_FAST_CNT) return launch_primary_t<VRT_TRAVERSAL_DF_FAST_CNT, false>(p, s);
     if (t == VRT_TRAVERSAL_BRICK) return launch_primary_t<VRT_TRAVERSAL_BRICK, false>(p, s);
+    if (t == VRT_TRAVERSAL_BRICK_CNT) return launch_primary_t<VRT_TRAVERSAL_BRICK_CNT, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_primary_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_primary_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_DFJ) return launch_primary_t<VRT_TRAVERSAL_DFJ, false>(p, s);
@@ -1548,6 +1553,7 @@ hipError_t launch_shade(const GeomParams& p, hipStream_t s)
     if (t == VRT_TRAVERSAL_DF_FAST) return launch_shade_t<VRT_TRAVERSAL_DF_FAST, false>(p, s);
     if (t == VRT_TRAVERSAL_DF_FAST_CNT) return launch_shade_t<VRT_TRAVERSAL_DF_FAST_CNT, false>(p, s);
     if (t == VRT_TRAVERSAL_BRICK) return launch_shade_t<VRT_TRAVERSAL_BRICK, false>(p, s);
+    if (t == VRT_TRAVERSAL_BRICK_CNT) return launch_shade_t<VRT_TRAVERSAL_BRICK_CNT, false>(p, s);
     if (t == VRT_TRAVERSAL_DENSE) return launch_shade_t<VRT_TRAVERSAL_DENSE, false>(p, s);
     if (t == VRT_TRAVERSAL_DF) return launch_shade_t<VRT_TRAVERSAL_DF, false>(p, s);
     if (t == VRT_TRAVERSAL_DFJ) return launch_shade_t<VRT_TRAVERSAL_DFJ, false>(p, s);

@@ -43,6 +43,7 @@
 #define VRT_TRAVERSAL_BRICK 6     // brick scenes (vrt_scene_from_bricks): DF over a two-level clearance; chosen by AUTO
 #define VRT_TRAVERSAL_DF_FAST 7   // internal: DF through the hand-written look-up loop (trace_df_fast); chosen by the host
 #define VRT_TRAVERSAL_DF_FAST_CNT 8   // internal: the same through the loops' counting twins (VRT_FLAG_MARCHED_COUNTS / VRT_FLAG_LOOKUP_COUNTS)
+#define VRT_TRAVERSAL_BRICK_CNT 9     // internal: the brick march with its counters (the same flags, and every launch that fills iteration-count planes)
 
 namespace vrt {
 
@@ -1903,7 +1904,7 @@ VRT_HD uint64_t brick_entry_pack(uint32_t ptr, const uint8_t coarse[8])
 // development build only: look-ups of the brick march by kind, summed over the lanes of all rays (vrt_debug_counters)
 __device__ unsigned long long g_vrt_brick_counts[4];   // lanes looking up, ... in an occupied brick, ... that found a solid voxel, ... in the border / an open brick
 #endif
-VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_t oct, int sx, int sy, int sz, uint32_t& material)
+VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_t oct, int sx, int sy, int sz, uint32_t& material, uint32_t* bytes = nullptr)
 {
     const uint32_t bx = (uint32_t)((mx >> 3) + 1), by = (uint32_t)((my >> 3) + 1), bz = (uint32_t)((mz >> 3) + 1);   // (-1 >> 3 = -1: the border brick)
     const uint32_t bi = bx + (uint32_t)mul24((int)by, v.pbx) + (uint32_t)mul24((int)bz, v.pbx * v.pby);
@@ -1921,7 +1922,9 @@ VRT_HD uint32_t brick_clear(const VolumeView& v, int mx, int my, int mz, uint32_
         const uint32_t l = lx | (ly << 3) | (lz << 6);
         clear = v.bfine[(size_t)(ptr - 1u) * 4096u + (size_t)(oct * 512u + l)];
         if (clear == 0u) material = v.bpool[(size_t)(ptr - 1u) * 512u + (size_t)l];
+        if (bytes) *bytes += clear == 0u ? 2u : 1u;
     }
+    if (bytes) *bytes += 8u;
 #if defined(VRT_TRACE_COUNTERS) && defined(__HIP_DEVICE_COMPILE__)
     {
         const bool occb = c == 0u && ptr - 1u < 0xFFFFFEu;
@@ -1973,12 +1976,16 @@ __device__ __forceinline__ void axis_run(float& x, float dx, float T)
 // every lane steps each axis on its own while its sideDist is <= the lane's threshold min(side + (c - 1) delta) (1 - 2^-16) --
 // one compare and one addition per step, every lane its own clearance.  Entered only by waves none of whose rays can take
 // maxSteps iterations (trace_brick); primary, bounce and shadow rays.
-template <class STATS>
+template <class STATS, bool CNT = false>
 __device__ __forceinline__ void brick_march_thresh(const VolumeView& v, DdaState& s, f3 dir, RayInt& r, STATS& stats)
 {
     asm volatile("" : "+v"(s.dx), "+v"(s.dy), "+v"(s.dz));
     uint64_t kx = __ballot((s.mask & 1u) != 0u), ky = __ballot((s.mask & 2u) != 0u), kz = __ballot((s.mask & 4u) != 0u);
     uint32_t lmask = s.mask, material = 0u, clear = 63u;
+    // (CNT, VRT_TRAVERSAL_BRICK_CNT: the steps the axes take, which is the iteration count unless two of them tie, and the bytes the
+    // look-ups ask for; the product kernels are the CNT = false instantiations)
+    constexpr bool cnt = CNT;
+    uint32_t steps = 0u, bytes = 0u;
     bool done = oob(v, s.mx, s.my, s.mz);
     const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
     const float kInf = u2f(0x7F800000u);
@@ -1988,7 +1995,7 @@ __device__ __forceinline__ void brick_march_thresh(const VolumeView& v, DdaState
     for (uint32_t guard = 0; guard < 16384u; guard++) {
         if (!done) {
             uint32_t m = 0u;
-            clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m);
+            clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m, cnt ? &bytes : nullptr);
             st_lookup(stats);
             if (clear == 0u) {                                 // solid, the border, or an open brick
                 if (!oob(v, s.mx, s.my, s.mz)) material = m;
@@ -2017,13 +2024,15 @@ __device__ __forceinline__ void brick_march_thresh(const VolumeView& v, DdaState
             axis_run(s.sdy, s.dy, T);
             axis_run(s.sdz, s.dz, T);
         }
-        s.mx += steps_signed(s.sdx - ox, gx); s.my += steps_signed(s.sdy - oy, gy); s.mz += steps_signed(s.sdz - oz, gz);
+        const int nx = steps_signed(s.sdx - ox, gx), ny = steps_signed(s.sdy - oy, gy), nz = steps_signed(s.sdz - oz, gz);
+        s.mx += nx; s.my += ny; s.mz += nz;
+        if (cnt) steps += (uint32_t)((nx < 0 ? -nx : nx) + (ny < 0 ? -ny : ny) + (nz < 0 ? -nz : nz));
     }
-    finish(s, material, lmask, 0u, r);
+    finish(s, material, lmask, cnt ? (v.count_lookups != 0u ? bytes : steps + (material != 0u ? 1u : 0u)) : 0u, r);
 }
 #endif
 
-template <class STATS, bool ANYHIT = false>
+template <class STATS, bool ANYHIT = false, bool CNT = false>
 VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -2040,7 +2049,7 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
     if (__builtin_amdgcn_readfirstlane((int)v.df_thresh) != 0) {
         const float bound = s.tspan * ((fabsf(dir.x) + fabsf(dir.y)) + fabsf(dir.z)) * 1.001f + 8.0f;
         if (__ballot(!oob(v, s.mx, s.my, s.mz) && !(bound < (float)maxSteps)) == 0ull) {
-            brick_march_thresh(v, s, dir, r, stats);
+            brick_march_thresh<STATS, CNT>(v, s, dir, r, stats);
             return;
         }
     }
@@ -2050,7 +2059,7 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
 #else
     bool k0 = (s.mask & 1u) != 0u, k1 = (s.mask & 2u) != 0u, k2 = (s.mask & 4u) != 0u;
 #endif
-    uint32_t material = 0, fetches = 0;
+    uint32_t material = 0, fetches = 0, lk_bytes = 0;
     bool done = oob(v, s.mx, s.my, s.mz);
     uint32_t clear = 63u;
     const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
@@ -2069,7 +2078,7 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
 #endif
             } else {
                 uint32_t m = 0u;
-                clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m);
+                clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m, CNT ? &lk_bytes : nullptr);
                 st_lookup(stats);
 #if defined(VRT_TRACE_COUNTERS)
                 n_look++;
@@ -2125,6 +2134,7 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
 #endif
         i += kw;
     }
+    if (CNT && v.count_lookups != 0u) fetches = lk_bytes;       // (VRT_FLAG_LOOKUP_COUNTS: the bytes the look-ups asked for)
 #if defined(__HIP_DEVICE_COMPILE__)
     finish(s, material, lmask, fetches, r);
 #if defined(VRT_TRACE_COUNTERS)
@@ -2138,7 +2148,7 @@ VRT_HD void trace_brick(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps
 #if defined(__HIP_DEVICE_COMPILE__)
 // The brick march for rays that point every way (AO): every lane spends its own clearance, up to VRT_OWN_CAP iterations per
 // look (df_any_loop's scheme in the generic loop: an iteration runs under the ballot of the lanes that have some left).
-template <class STATS>
+template <class STATS, bool CNT = false>
 __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f3 dir, uint32_t maxSteps, RayInt& r, STATS& stats)
 {
     DdaState s;
@@ -2150,7 +2160,7 @@ __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f
     }
     dda_rest(dir, s);
     asm volatile("" : "+v"(s.dx), "+v"(s.dy), "+v"(s.dz));
-    uint32_t material = 0u, fetches = 0u, i = 0u;             // i: iterations THIS lane has taken
+    uint32_t material = 0u, fetches = 0u, i = 0u, lk_bytes = 0u;             // i: iterations THIS lane has taken
     bool done = oob(v, s.mx, s.my, s.mz);
     const uint32_t oct = (uint32_t)(s.sx > 0) | ((uint32_t)(s.sy > 0) << 1) | ((uint32_t)(s.sz > 0) << 2);
     const float kInf = u2f(0x7F800000u);
@@ -2161,7 +2171,7 @@ __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f
             if (i >= maxSteps) { done = true; fetches = i; }
             else {
                 uint32_t m = 0u;
-                const uint32_t clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m);
+                const uint32_t clear = brick_clear(v, s.mx, s.my, s.mz, oct, s.sx, s.sy, s.sz, m, CNT ? &lk_bytes : nullptr);
                 st_lookup(stats);
                 if (clear == 0u) {
                     if (oob(v, s.mx, s.my, s.mz)) fetches = i;
@@ -2182,10 +2192,10 @@ __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f
         s.mx += steps_signed(s.sdx - ox, gx); s.my += steps_signed(s.sdy - oy, gy); s.mz += steps_signed(s.sdz - oz, gz);
         i += own;
     }
-    finish(s, material, s.mask, fetches, r);
+    finish(s, material, s.mask, (CNT && v.count_lookups != 0u) ? lk_bytes : fetches, r);
 }
 #else
-template <class STATS>
+template <class STATS, bool CNT = false>
 VRT_HD void trace_brick_own(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 #endif
 
@@ -2536,6 +2546,10 @@ VRT_HD void trace_int(const VolumeView& v, OP o2, OP o3, f3 start, f3 dir,
         NoStats ns;
         if (ANYHIT && OWN && v.df_own) trace_brick_own(v, start, dir, maxSteps, r, ns);
         else trace_brick<NoStats, ANYHIT>(v, start, dir, maxSteps, r, ns);
+    } else if (TRAV == VRT_TRAVERSAL_BRICK_CNT) {
+        NoStats ns;
+        if (ANYHIT && OWN && v.df_own) trace_brick_own<NoStats, true>(v, start, dir, maxSteps, r, ns);
+        else trace_brick<NoStats, ANYHIT, true>(v, start, dir, maxSteps, r, ns);
     } else if (TRAV == VRT_TRAVERSAL_DF_FAST) {
         NoStats ns;
         trace_df_fast<NoStats, ANYHIT, PF, OWN>(v, start, dir, maxSteps, r, ns);
