@@ -149,7 +149,7 @@ int  vrt_ctx_set_stream(vrt_ctx* ctx, void* hip_stream);
 int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle(), engine.cpp:351 */
 /* Development switches of a context (no reference analogue; the reference's counterpart is recompiling a shader): each changes
  * speed only, never a result -- the tests render "the same frame without X" with them.  Name (default), who looks at it:
- *   every vrt_render_geometry* call:  "tile_tags" (1), "box_rect" (1), "fast_loop" (1), "thresh_runs" (1), "ao_batch" (1), "hit_table" (1),
+ *   every vrt_render_geometry* call:  "tile_tags" (1), "box_rect" (1), "fast_loop" (1), "thresh_runs" (1), "ao_batch" (1), "tags_async" (0: the tags of a launch on a stream of their own measured slower), "hit_table" (1),
  *                                     "no_bounce_kernel" (1), "packed_bounces" (1), "sky_fast" (1),
  *                                     "xcd_regions" (0 -- until round 3 VRT_XCD_REGIONS was on by default; as a three-dimensional grid the
  *                                     form ran 30.0 or 33.6 us per bench frame from one process to the next, so it is opt-in now)

@@ -49,6 +49,9 @@ struct DevOptions {
     int fast_loop = 1;         // AUTO / DF through the hand-written look-up loop
     int no_bounce_kernel = 1;  // the megakernel without its bounce loop when nothing can bounce
     int packed_bounces = 1;    // the megakernel's bounce chain as one word per hit (no stack of hits in scratch)
+    int tags_async = 0;        // the tile tags of a launch on a stream of their own while the context's stream is still busy with the launch before
+                               // (off: measured SLOWER -- one frame per call, 1 / 2 / 3 contexts in flight: 53.8 / 31.0 / 26.9 us per frame with the
+                               // tags on the context's stream, 58.5 / 34.1 / 52.2 us on their own; tools/exp_r4_inflight.py)
     int ao_batch = 1;          // the hand-written loop takes a lane's AO rays two at a time, back to back (df_ao_batch_loop)
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
     int thresh_runs = 1;       // primary rays through df_prim_loop (long runs by threshold)
@@ -67,7 +70,7 @@ static const OptName kOptNames[] = {
     {"tile_tags", "VRT_TILE_TAGS", &DevOptions::tile_tags}, {"box_rect", "VRT_BOX_RECT", &DevOptions::box_rect},
     {"xcd_regions", "VRT_XCD_REGIONS", &DevOptions::xcd_regions}, {"fast_loop", "VRT_FAST_LOOP", &DevOptions::fast_loop},
     {"no_bounce_kernel", "VRT_NO_BOUNCE_KERNEL", &DevOptions::no_bounce_kernel}, {"sky_fast", "VRT_SKY_FAST", &DevOptions::sky_fast},
-    {"packed_bounces", "VRT_PACKED_BOUNCES", &DevOptions::packed_bounces}, {"ao_batch", "VRT_AO_BATCH", &DevOptions::ao_batch},
+    {"packed_bounces", "VRT_PACKED_BOUNCES", &DevOptions::packed_bounces}, {"ao_batch", "VRT_AO_BATCH", &DevOptions::ao_batch}, {"tags_async", "VRT_TAGS_ASYNC", &DevOptions::tags_async},
     {"hit_table", "VRT_HIT_TABLE", &DevOptions::hit_table},
     {"thresh_runs", "VRT_THRESH_RUNS", &DevOptions::thresh_runs}, {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
     {"denoise_verified", "VRT_DENOISE_VERIFIED", &DevOptions::denoise_verified}, {"denoise_guard_div8", "VRT_DENOISE_GUARD_DIV8", &DevOptions::denoise_guard_div8},
@@ -99,10 +102,17 @@ struct vrt_ctx {
     bool tab_busy[kTabRing] = {false, false, false, false};
     int tab_next = 0;
     hipStream_t upload_stream = nullptr;
-    // tile tags of the latest launch (k_tile_tags): one word per 8x8-pixel block and frame, valid where == tile_gen
-    uint32_t* tile_tags = nullptr;
-    size_t tile_tags_words = 0;
+    // tile tags (k_tile_tags): one word per 8x8-pixel block and frame, valid where == tile_gen.  Two buffers taken in turn: the tags
+    // of launch N + 1 are made on a stream of their own while launch N still traces (they depend on the camera alone), and must not
+    // land in the buffer launch N reads
+    uint32_t* tile_tags[2] = {nullptr, nullptr};
+    size_t tile_tags_words[2] = {0, 0};
     uint32_t tile_gen = 0;
+    int tag_flip = 0;
+    hipStream_t tag_stream = nullptr;
+    hipEvent_t tag_done[2] = {nullptr, nullptr};      // on tag_stream: the tags in buffer b are complete
+    hipEvent_t tag_read[2] = {nullptr, nullptr};      // on stream: the launch that read buffer b is done
+    bool tag_read_valid[2] = {false, false};
     // colorHit() over materials x normals for launches without secondary rays (k_hit_colors), and what it was made from
     uint32_t* hit_colors = nullptr;
     uint64_t hit_scene_gen = 0;
@@ -178,7 +188,12 @@ void vrt_ctx_destroy(vrt_ctx* c)
     hipStreamSynchronize(c->stream);
     if (c->records) hipFree(c->records);
     if (c->hit_list) hipFree(c->hit_list);
-    if (c->tile_tags) hipFree(c->tile_tags);
+    if (c->tag_stream) { hipStreamSynchronize(c->tag_stream); hipStreamDestroy(c->tag_stream); }
+    for (int b = 0; b < 2; b++) {
+        if (c->tile_tags[b]) hipFree(c->tile_tags[b]);
+        if (c->tag_done[b]) hipEventDestroy(c->tag_done[b]);
+        if (c->tag_read[b]) hipEventDestroy(c->tag_read[b]);
+    }
     if (c->hit_colors) hipFree(c->hit_colors);
     if (c->den_counts) hipFree(c->den_counts);
     if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
@@ -1084,6 +1099,7 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
         p.hit_colors = c->hit_colors;
     }
     // tile tags: dense scenes, frames with a box rectangle, launches that do not report the reference's iteration counts
+    int tag_buf = -1;
     {
         bool want = c->opt.tile_tags != 0 && s->cells_ok && !counts && W <= 8128 && H <= 8128;
         bool any = false;
@@ -1095,30 +1111,60 @@ static int render_frames(vrt_ctx* c, const vrt_scene* s, int n, const vrt_push* 
             p.tags_per_frame = p.tags_x * p.tags_y + 1u;
             // (without tags: one word per frame that says "trace every block")
             const size_t words = (size_t)p.tags_per_frame * (size_t)n;
-            if (c->tile_tags_words < words) {
+            const int b = c->tag_flip; c->tag_flip ^= 1;
+            tag_buf = b;
+            if (c->tile_tags_words[b] < words) {
                 HIPCHK(hipStreamSynchronize(c->stream));
-                if (c->tile_tags) hipFree(c->tile_tags);
-                c->tile_tags = nullptr; c->tile_tags_words = 0;
-                HIPCHK(hipMalloc((void**)&c->tile_tags, words * sizeof(uint32_t)));
-                HIPCHK(hipMemsetAsync(c->tile_tags, 0, words * sizeof(uint32_t), c->stream));
-                c->tile_tags_words = words;
+                if (c->tag_stream) HIPCHK(hipStreamSynchronize(c->tag_stream));
+                if (c->tile_tags[b]) hipFree(c->tile_tags[b]);
+                c->tile_tags[b] = nullptr; c->tile_tags_words[b] = 0;
+                HIPCHK(hipMalloc((void**)&c->tile_tags[b], words * sizeof(uint32_t)));
+                HIPCHK(hipMemsetAsync(c->tile_tags[b], 0, words * sizeof(uint32_t), c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                c->tile_tags_words[b] = words;
+                c->tag_read_valid[b] = false;
             }
             if (++c->tile_gen == 0u) {                                    // (wrapped: stale tags could match again)
-                HIPCHK(hipMemsetAsync(c->tile_tags, 0, c->tile_tags_words * sizeof(uint32_t), c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->tag_stream) HIPCHK(hipStreamSynchronize(c->tag_stream));
+                for (int q = 0; q < 2; q++)
+                    if (c->tile_tags[q]) HIPCHK(hipMemsetAsync(c->tile_tags[q], 0, c->tile_tags_words[q] * sizeof(uint32_t), c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
                 c->tile_gen = 1u;
             }
-            p.tile_tags = c->tile_tags; p.tile_gen = c->tile_gen;
+            p.tile_tags = c->tile_tags[b]; p.tile_gen = c->tile_gen;
             if (tags) {
                 p.cells = s->cells; p.n_cells = s->n_cells; p.cell_size = s->bricks ? 8u : 4u;
-                HIPCHK(launch_tile_tags(p, c->stream));
+                // The tags depend on the cameras alone, not on anything the context's stream is still computing: while that stream is
+                // busy (the caller runs ahead of the device: a frame loop, a batch loop) they are made on a stream of their own, under
+                // the previous launch's tail, and the launch waits for an event instead of a kernel; on an idle device the second
+                // stream would only add the event's latency.  (context option tags_async = 0: always on the context's stream)
+                const bool async = c->opt.tags_async != 0 && hipStreamQuery(c->stream) == hipErrorNotReady;
+                if (async) {
+                    if (!c->tag_stream) {
+                        HIPCHK(hipStreamCreateWithFlags(&c->tag_stream, hipStreamNonBlocking));
+                        for (int q = 0; q < 2; q++) {
+                            HIPCHK(hipEventCreateWithFlags(&c->tag_done[q], hipEventDisableTiming));
+                            HIPCHK(hipEventCreateWithFlags(&c->tag_read[q], hipEventDisableTiming));
+                        }
+                    }
+                    if (c->tag_read_valid[b]) HIPCHK(hipStreamWaitEvent(c->tag_stream, c->tag_read[b], 0));     // the launch that last read this buffer
+                    if (tab >= 0) HIPCHK(hipStreamWaitEvent(c->tag_stream, c->tab_uploaded[tab], 0));            // the slots the tag kernel reads
+                    HIPCHK(launch_tile_tags(p, c->tag_stream));
+                    HIPCHK(hipEventRecord(c->tag_done[b], c->tag_stream));
+                    HIPCHK(hipStreamWaitEvent(c->stream, c->tag_done[b], 0));
+                } else {
+                    HIPCHK(launch_tile_tags(p, c->stream));
+                }
             } else {
                 // every frame's one word = tile_gen
                 std::vector<uint32_t> ones((size_t)n, c->tile_gen);
-                HIPCHK(hipMemcpyAsync(c->tile_tags, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipMemcpyAsync(c->tile_tags[b], ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
             }
         }
     }
     HIPCHK(launch_primary(p, c->stream));
+    if (tag_buf >= 0 && c->tag_stream) { HIPCHK(hipEventRecord(c->tag_read[tag_buf], c->stream)); c->tag_read_valid[tag_buf] = true; }
     if (tab >= 0) { HIPCHK(hipEventRecord(c->tab_consumed[tab], c->stream)); c->tab_busy[tab] = true; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev_prim1, c->stream));
     if (!p.fused_shade) HIPCHK(launch_shade(p, c->stream));

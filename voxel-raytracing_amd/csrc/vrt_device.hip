@@ -424,7 +424,7 @@ __device__ __forceinline__ float decode_snorm8(int32_t c)
 // (kernels of VRT_TRAVERSAL_DF_FAST never fill iteration-count planes -- vrt_api.hip sends every launch that has them to the counting twins,
 // VRT_TRAVERSAL_DF_FAST_CNT -- so for them `fetches` is dead and the compiler drops it: VRT_COUNTS(TRAV))
 #define VRT_COUNTS(TRAV) ((TRAV) != VRT_TRAVERSAL_DF_FAST && (TRAV) != VRT_TRAVERSAL_BRICK)
-struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; f3 noise; bool have_noise;
+struct PixCtx { int px, py; uint32_t fetches, rays; const vrt_push* pc; f3 noise;
                 uint32_t ldsw; };    // ldsw: byte address of the wave's VRT_AO_SLOT bytes of LDS (df_ao_pool_loop): kernels that trace AO rays through the hand-written loop
 
 // skyColor, voxel_volume.frag:98-105
@@ -514,13 +514,13 @@ __device__ __forceinline__ f3 random_dir(const DevScene& s, const vrt_push& pc, 
     uint32_t offset = num * 32u + pc.frame % 32u;
     const float g = 1.22074408460575947536f;
     const float a0 = 1.0f / g, a1 = 1.0f / (g * g), a2 = 1.0f / ((g * g) * g);
-    if (!c.have_noise) {
+    {   // (the pixel's blue-noise texel is fetched anew for every sample: kept across the traces it cost four registers and, through the
+        // branch around the fetch, a second copy of everything after it -- 1 350 instructions of the megakernel)
         float pxf = ((float)c.px + 0.5f) / 512.0f + 0.5f;
         float pyf = ((float)c.py + 0.5f) / 512.0f + 0.5f;
         uint32_t tx = wrap_texel(pxf, s.noise_w), ty = wrap_texel(pyf, s.noise_h);
         const uchar4 t = reinterpret_cast<const uchar4*>(s.noise)[(size_t)ty * s.noise_w + tx];
         c.noise = mk3(decode_unorm8(t.x), decode_unorm8(t.y), decode_unorm8(t.z));          // = t / 255.0f, exactly
-        c.have_noise = true;
     }
     float fo = (float)offset;
     float n0 = c.noise.x + fo * a0;
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_hit_colors(const GeomParams P, uint32_t
         RayHit h;
         h.material = material; h.pos = mk3(0.0f, 0.0f, 0.0f); h.dir = mk3(0.0f, 0.0f, 0.0f);
         h.normal = hit_normal(mask, sx, sy, sz); h.ncode = code;
-        PixCtx c; c.px = 0; c.py = 0; c.fetches = 0; c.rays = 0; c.pc = nullptr; c.have_noise = false; c.ldsw = 0u;
+        PixCtx c; c.px = 0; c.py = 0; c.fetches = 0; c.rays = 0; c.pc = nullptr; c.ldsw = 0u;
         OccT<false> occ; occ.o2 = nullptr; occ.o3 = nullptr;
         const f3 col = color_hit<VRT_TRAVERSAL_DF_FAST, OccT<false>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);
         c8 = (uint32_t)unorm8(col.x) | ((uint32_t)unorm8(col.y) << 8) | ((uint32_t)unorm8(col.z) << 16);
@@ -1098,11 +1098,14 @@ __device__ __forceinline__ void store_color(const vrt_frame& f, f3 col, size_t i
 // MODE 2: megakernel -- the lanes that hit go on to trace their AO / shadow / bounce rays in this same kernel, so that
 //         the secondary rays' latency hides under the primary work of the other waves (a separate K2 launch has a
 //         single round of waves and is bound by the longest ray's dependency chain).
+#ifndef VRT_CHAIN_WAVES
+#define VRT_CHAIN_WAVES 7     // (development: the packed-chain megakernels at 6 or 5 waves per SIMD, i.e. 80 / 96 VGPRs)
+#endif
 #ifndef VRT_MODE4_WAVES
 #define VRT_MODE4_WAVES 7     // (development: 8 forces the megakernel without its bounce loop into 64 VGPRs, at the price of 12 B of scratch per lane)
 #endif
 template <int TRAV, bool OCC_LDS, int MODE, bool TABLE, int MAP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((MODE == 4 && TRAV == VRT_TRAVERSAL_DF_FAST) ? VRT_MODE4_WAVES : 7), 8))) void k_primary(const GeomParams P)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((MODE == 4 && TRAV == VRT_TRAVERSAL_DF_FAST) ? VRT_MODE4_WAVES : (MODE >= 5 ? VRT_CHAIN_WAVES : 7)), 8))) void k_primary(const GeomParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_occ[];
     // the tile map arrives with one 64-byte scalar load (and one wait) before anything depends on it
@@ -1311,7 +1314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((MODE == 4
     if (MODE != 0) {                                           // 1: primary only; 2: megakernel; 4: megakernel, nothing can bounce
         f3 col;
         if (hit) {
-            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame); c.have_noise = false;
+            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame);
             c.ldsw = (uint32_t)(uintptr_t)(lds_u64_ptr)lds_occ + (uint32_t)wave * (uint32_t)VRT_AO_SLOT;   // (the hand-written loop's kernels are launched with a pool per wave)
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
@@ -1323,7 +1326,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((MODE == 4
         } else {
             col = sky_color(s, dir);
         }
+#ifdef VRT_EXP_LATE_INDEX
+        {   // the pixel's indices once more, from px and py alone: nothing but those two stays live across the secondary rays
+            int pxl = px, pyl = py;
+            asm volatile("" : "+v"(pxl), "+v"(pyl));
+            const size_t il = (size_t)pyl * (size_t)W + (size_t)pxl;
+            store_color(f, col, il, (uint32_t)il, ((uint32_t)(yp0 + (pyl - y0)) * (uint32_t)W + (uint32_t)pxl) << 2);
+        }
+#else
         store_color(f, col, i, i32, ((uint32_t)(yp0 + (py - y0)) * (uint32_t)W + (uint32_t)px) << 2);
+#endif
 #ifdef VRT_EXP_STAMPS
         if (f.motion) *gptr<vrt_f2>(f.motion, i32 << 3) = (vrt_f2){__uint_as_float((uint32_t)t_begin), __uint_as_float((uint32_t)wall_clock64())};
 #endif
@@ -1367,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_shade(const GeomParams P)
     h.pos = mk3(__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z));
     uint32_t mask = (rec.w >> 8) & 7u;
     int sx = (int)((rec.w >> 11) & 3u) - 1, sy = (int)((rec.w >> 13) & 3u) - 1, sz = (int)((rec.w >> 15) & 3u) - 1;
-    PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &P.slot[0].pc; c.have_noise = false;
+    PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = &P.slot[0].pc;
     c.ldsw = (uint32_t)(uintptr_t)(lds_u64_ptr)lds_occ + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (uint32_t)VRT_AO_SLOT;
     h.normal = hit_normal(mask, sx, sy, sz);
     {
