@@ -26,4 +26,18 @@ void tags_project(int n, const float* cams, const float* cells, int rcp_ulps, fl
     g_tag_rcp_ulps = 0;
 }
 
+// bands: 2 floats each (ylo, yhi); out: 1 byte each: the cell is certainly outside the band's rows (tag_band_cull)
+void tags_band_cull(int n, const float* cams, const float* cells, const float* bands, int rcp_ulps, unsigned char* out)
+{
+    g_tag_rcp_ulps = rcp_ulps;
+    for (int i = 0; i < n; i++) {
+        TagCam k;
+        const float* c = cams + 14 * i;
+        for (int a = 0; a < 3; a++) { k.U[a] = c[a]; k.V[a] = c[3 + a]; k.C[a] = c[6 + a]; k.cam[a] = c[9 + a]; }
+        k.W = c[12]; k.H = c[13];
+        out[i] = tag_band_cull(k, cells + 4 * i, cells[4 * i + 3], bands[2 * i], bands[2 * i + 1]) ? 1 : 0;
+    }
+    g_tag_rcp_ulps = 0;
+}
+
 } // extern "C"

@@ -29,6 +29,7 @@ def tags():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB, SRC])
     l = C.CDLL(LIB)
     l.tags_project.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    l.tags_band_cull.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     return l
 
 
@@ -135,3 +136,46 @@ def test_bound_is_a_small_fraction_of_a_pixel_for_the_bench_camera(tags, vrt):
     cells = np.array([[x, y, z, 6.0] for x in (-1.0, 123.0, 251.0) for y in (-1.0, 123.0, 251.0) for z in (-1.0, 123.0, 251.0)], np.float32)
     out = project(tags, np.repeat(cam[None], len(cells), 0), cells)
     assert (out[:, 6] == 0).all() and out[:, 4].max() < 0.01 and out[:, 5].max() < 0.01, out[:, 4:7]
+
+
+@pytest.mark.parametrize("kind", ["ordinary", "jitter", "skewed", "far", "grazing"])
+def test_band_cull_never_drops_a_cell_the_band_can_see(tags, kind):
+    """tag_band_cull (a rank of a sharded launch skips the cells whose rows are somebody else's): whenever it says "outside", the
+    TRUE row range of the cell -- exact rational arithmetic -- grown by the tags' margin less the half pixel of the pixel-centre
+    convention must miss the band; and for ordinary cameras it does drop most of what lies outside (the test is not vacuous)"""
+    rng = np.random.default_rng({"ordinary": 11, "jitter": 12, "skewed": 13, "far": 14, "grazing": 15}[kind])
+    n = 1500
+    cams = np.stack([camera(rng, kind if kind != "grazing" else "ordinary") for _ in range(n)])
+    cells = np.stack([cell(rng, cams[i], kind) for i in range(n)])
+    H = cams[:, 13]
+    # bands: an eighth of the screen somewhere, half of them chosen to hug the cell's own rows (the hard cases)
+    bands = np.zeros((n, 2), np.float32)
+    trues = [true_rect(cams[i], cells[i]) for i in range(n)]
+    for i in range(n):
+        h = float(H[i])
+        y0 = rng.uniform(0, h * 7 / 8)
+        t = trues[i]
+        if t is not None and t[4] > 0 and rng.random() < 0.5:
+            edge = float(t[3]) if rng.random() < 0.5 else float(t[2]) - h / 8
+            y0 = edge + rng.uniform(-4, 4)
+        bands[i] = (np.floor(y0), np.floor(y0) + np.ceil(h / 8))
+    culled = outside = 0
+    for ulps in (-1, 0, 1):
+        out = np.zeros(n, np.uint8)
+        l = tags
+        l.tags_band_cull(n, np.ascontiguousarray(cams).ctypes.data, np.ascontiguousarray(cells).ctypes.data, bands.ctypes.data, ulps, out.ctypes.data)
+        for i in range(n):
+            t = trues[i]
+            if t is None or t[4] <= 0:
+                assert not out[i], (kind, i, "a cell with a corner on or behind the camera plane is never judged")
+                continue
+            Y0, Y1 = t[2], t[3]
+            ylo, yhi = Fr(float(bands[i, 0])), Fr(float(bands[i, 1]))
+            sees = not (Y1 + Fr(3, 2) < ylo or Y0 - Fr(3, 2) > yhi)          # margin 2 px, half a pixel of it the pixel-centre convention's
+            if out[i]:
+                assert not sees, (kind, i, ulps, float(Y0), float(Y1), float(ylo), float(yhi))
+                culled += 1
+            far_out = (Y1 + 3 < ylo or Y0 - 3 > yhi) and t[4] > Fr(1, 2)
+            outside += far_out
+    if kind in ("ordinary", "jitter"):
+        assert culled > 0.9 * outside > 0, (culled, outside)

@@ -1440,6 +1440,12 @@ __global__ __launch_bounds__(256) void k_tile_tags(const GeomParams P)
     tc.C[0] = g.cd.x + g.jx; tc.C[1] = g.cd.y + g.jy; tc.C[2] = g.cd.z;
     tc.cam[0] = cam[0]; tc.cam[1] = cam[1]; tc.cam[2] = cam[2];
     tc.W = g.W; tc.H = g.H;
+    // a rank that owns ONE band of rows (the banded assignment of a multi-GPU batch): seven cells in eight of an 8-GPU step lie
+    // outside it, and two linear forms say so without the eight corners' divisions (vrt_tags.h tag_band_cull, with its own bound)
+    if (P.sh.nranks > 1) {
+        const int rows = P.sh.strip_rows, total = ((int)g.H + rows - 1) / rows;
+        if (shard_rank + P.sh.nranks >= total && tag_band_cull(tc, lo, ext, (float)(shard_rank * rows), (float)(shard_rank * rows + rows))) return;
+    }
     float x0, x1, y0, y1, ex, ey;
     const int st = tag_project(tc, lo, ext, x0, x1, y0, y1, ex, ey);
     bool all = (st & 1) != 0;

@@ -101,4 +101,54 @@ VRT_HD int tag_project(const TagCam& k, const float lo[3], float ext, float& x0,
     return (all ? 1 : 0) | (loose ? 2 : 0);
 }
 
+// A rank of a sharded launch traces one band of pixel rows [ylo, yhi) of every frame, so seven cells in eight of an 8-GPU step's
+// tag kernel project onto rows that are somebody else's.  This says so without the eight divisions: a cell's pixel row is
+// y = (B / L) H/2 + H/2, so "every corner above the band" is  B sgn - t L sgn < 0  with t = (ylo - margin - H/2) / (H/2)  -- a
+// LINEAR function of the corner, whose largest value over the box is its value at one corner plus the positive parts of its
+// three increments; likewise "every corner below".  Only cells whose corners all lie in front of the camera plane with certainty
+// are judged.  Rounding: B and L carry 7u Q1 and 7u Q2 (above), t two roundings on a value below 2 in magnitude for any band on
+// the screen, the combination three more: the verdict is given only when it holds by more than 16u (Q1 + (|t| + 1) Q2).
+// Returns true: no pixel row of [ylo, yhi), grown by the tags' margin, sees the cell -- the same cells the full projection would
+// give no tag in the band (up to both computations' bounds, each of which errs on the side of tagging).
+VRT_HD bool tag_band_cull(const TagCam& k, const float lo[3], float ext, float ylo, float yhi)
+{
+    const float* U = k.U; const float* V = k.V; const float* C = k.C;
+    const float c0[3] = {V[1] * C[2] - V[2] * C[1], V[2] * C[0] - V[0] * C[2], V[0] * C[1] - V[1] * C[0]};   // V x C
+    const float c1[3] = {C[1] * U[2] - C[2] * U[1], C[2] * U[0] - C[0] * U[2], C[0] * U[1] - C[1] * U[0]};   // C x U
+    const float c2[3] = {U[1] * V[2] - U[2] * V[1], U[2] * V[0] - U[0] * V[2], U[0] * V[1] - U[1] * V[0]};   // U x V
+    const float m0[3] = {fabsf(V[1] * C[2]) + fabsf(V[2] * C[1]), fabsf(V[2] * C[0]) + fabsf(V[0] * C[2]), fabsf(V[0] * C[1]) + fabsf(V[1] * C[0])};
+    const float m1[3] = {fabsf(C[1] * U[2]) + fabsf(C[2] * U[1]), fabsf(C[2] * U[0]) + fabsf(C[0] * U[2]), fabsf(C[0] * U[1]) + fabsf(C[1] * U[0])};
+    const float m2[3] = {fabsf(U[1] * V[2]) + fabsf(U[2] * V[1]), fabsf(U[2] * V[0]) + fabsf(U[0] * V[2]), fabsf(U[0] * V[1]) + fabsf(U[1] * V[0])};
+    const float det = U[0] * c0[0] + U[1] * c0[1] + U[2] * c0[2];
+    const float mdet = fabsf(U[0]) * m0[0] + fabsf(U[1]) * m0[1] + fabsf(U[2]) * m0[2];
+    if (!(fabsf(det) > 1e-5f * mdet)) return false;            // (the sign of det decides what "in front" means: tag_project's own test)
+    const float sgn = det < 0.0f ? -1.0f : 1.0f;
+    const float p0[3] = {lo[0] - k.cam[0], lo[1] - k.cam[1], lo[2] - k.cam[2]};
+    const float B0 = (p0[0] * c1[0] + p0[1] * c1[1] + p0[2] * c1[2]) * sgn, L0 = (p0[0] * c2[0] + p0[1] * c2[1] + p0[2] * c2[2]) * sgn;
+    const float pa[3] = {fabsf(p0[0]) + ext, fabsf(p0[1]) + ext, fabsf(p0[2]) + ext};
+    const float Q1 = pa[0] * m1[0] + pa[1] * m1[1] + pa[2] * m1[2], Q2 = pa[0] * m2[0] + pa[1] * m2[1] + pa[2] * m2[2];
+    const float u = 5.9604645e-8f;
+    // every corner in front of the camera plane, with certainty: the smallest L sgn over the box
+    const float l0 = c2[0] * sgn * ext, l1 = c2[1] * sgn * ext, l2 = c2[2] * sgn * ext;
+    const float lmin = L0 + (fminf(l0, 0.0f) + fminf(l1, 0.0f) + fminf(l2, 0.0f));
+    if (!(lmin > 16.0f * u * Q2)) return false;
+    const float hh = 0.5f * k.H, rh = tag_rcp(hh);
+    const float m = VRT_TAG_MARGIN_PX;
+    const float tlo = ((ylo - m) - hh) * rh, thi = ((yhi + m) - hh) * rh;
+    const float b0 = c1[0] * sgn * ext, b1 = c1[1] * sgn * ext, b2 = c1[2] * sgn * ext;
+    {   // above the band: max over the corners of B - tlo L < -E
+        const float f0 = b0 - tlo * l0, f1 = b1 - tlo * l1, f2 = b2 - tlo * l2;
+        const float fmax = (B0 - tlo * L0) + (fmaxf(f0, 0.0f) + fmaxf(f1, 0.0f) + fmaxf(f2, 0.0f));
+        const float E = 16.0f * u * (Q1 + (fabsf(tlo) + 1.0f) * Q2);
+        if (fmax < -E) return true;
+    }
+    {   // below the band: min over the corners of B - thi L > E
+        const float f0 = b0 - thi * l0, f1 = b1 - thi * l1, f2 = b2 - thi * l2;
+        const float fmin = (B0 - thi * L0) + (fminf(f0, 0.0f) + fminf(f1, 0.0f) + fminf(f2, 0.0f));
+        const float E = 16.0f * u * (Q1 + (fabsf(thi) + 1.0f) * Q2);
+        if (fmin > E) return true;
+    }
+    return false;
+}
+
 } // namespace vrt
