@@ -52,7 +52,7 @@ struct DevOptions {
     int tags_async = 0;        // the tile tags of a launch on a stream of their own while the context's stream is still busy with the launch before
                                // (off: measured SLOWER -- one frame per call, 1 / 2 / 3 contexts in flight: 53.8 / 31.0 / 26.9 us per frame with the
                                // tags on the context's stream, 58.5 / 34.1 / 52.2 us on their own; tools/exp_r4_inflight.py)
-    int ao_batch = 1;          // the hand-written loop takes a lane's AO rays two at a time, back to back (df_ao_batch_loop)
+    int ao_batch = 1;          // the AO rays of a wave from a pool in LDS that every lane draws on (df_ao_pool_loop, brick_ao_pool)
     int sky_fast = 1;          // sky texel of waves that cannot hit anything by vrt_sky.h
     int thresh_runs = 1;       // primary rays through df_prim_loop (long runs by threshold)
     int hit_table = 1;         // launches without secondary rays take a hit's colour from the table of colorHit() over materials x normals

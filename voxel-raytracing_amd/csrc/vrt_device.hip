@@ -627,6 +627,32 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
         // calcAmbient's sum (frag:219-222): one addition of 1 / aoSamples per ray that hit -- the value depends on their number only
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t q = 0; q < ao_hits; q++) ambient += sample_frac;
+    } else if ((TRAV == VRT_TRAVERSAL_BRICK || TRAV == VRT_TRAVERSAL_BRICK_CNT) && __builtin_amdgcn_readfirstlane((int)s.vol.ao_batch) != 0) {
+        // brick scenes: the same pool in the generic loop (brick_ao_pool)
+        constexpr bool kCnt = TRAV == VRT_TRAVERSAL_BRICK_CNT;
+        const uint32_t ldsw = c.ldsw;
+        const uint64_t act = __ballot(true);
+        const uint32_t col = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        const uint32_t nact = (uint32_t)__builtin_popcountll(act);
+        __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 3072u + col * 4u);
+        cnt[0] = 0u;
+        if (kCnt) cnt[64] = 0u;
+        BrickAoLane lane;
+        brick_ao_rest(lane);
+        uint32_t next = 0u, looks = 0u;
+        for (uint32_t i = 0; i < st.ao_samples; i++) {
+            f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
+            f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
+            f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
+            brick_ao_store(s.vol, ldsw, col, o, dir);
+            next = 0u;
+            brick_ao_pool<kCnt>(s.vol, lane, ldsw, nact, i + 1u < st.ao_samples, next, st.ao_steps, looks);
+        }
+        ao_hits = cnt[0];
+        c.rays += st.ao_samples;
+        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : cnt[64];
+        float sample_frac = 1.0f / (float)st.ao_samples;
+        for (uint32_t q = 0; q < ao_hits; q++) ambient += sample_frac;
     } else {
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
@@ -1508,7 +1534,8 @@ static hipError_t launch_primary_t(const GeomParams& p, hipStream_t s)
     dim3 block(p.tile_h == 8 ? 64 : 256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
     // (the hand-written loop's AO batches: one slot of waiting rays per wave, df_ao_batch_loop)
-    if ((TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT) && p.fused_shade != 1) lds = (size_t)(block.x / 64u) * (size_t)VRT_AO_SLOT;
+    if ((TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK || TRAV == VRT_TRAVERSAL_BRICK_CNT) && p.fused_shade != 1)
+        lds = (size_t)(block.x / 64u) * (size_t)VRT_AO_SLOT;
     // (the product traversals with the tile map's form as a compile-time constant: block_to_tile)
     constexpr bool kProduct = TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK || TRAV == VRT_TRAVERSAL_BRICK_CNT;
     constexpr bool kCount = TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK_CNT;      // (counting launches: the general tile map only -- fewer kernels to build)
@@ -1538,7 +1565,7 @@ static hipError_t launch_shade_t(const GeomParams& p, hipStream_t s)
     // workgroups leave at once
     dim3 grid((unsigned)(((size_t)p.total_tiles * p.tile_w * p.tile_h + 255) / 256)), block(256);
     size_t lds = (OCC_LDS && (TRAV == VRT_TRAVERSAL_BITMASK || TRAV == VRT_TRAVERSAL_JUMP)) ? p.occ2_bytes + p.occ3_bytes : 0;
-    if (TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT) lds = 4u * (size_t)VRT_AO_SLOT;
+    if (TRAV == VRT_TRAVERSAL_DF_FAST || TRAV == VRT_TRAVERSAL_DF_FAST_CNT || TRAV == VRT_TRAVERSAL_BRICK || TRAV == VRT_TRAVERSAL_BRICK_CNT) lds = 4u * (size_t)VRT_AO_SLOT;
     hipLaunchKernelGGL((k_shade<TRAV, OCC_LDS>), grid, block, lds, s, p);
     return hipGetLastError();
 }

@@ -804,7 +804,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 
 // an AO ray as df_ao_pool_loop takes it up, and the LDS bytes of a wave's pool (11 dwords x 64 columns) + its two rows of counters
 struct AoRay { float x, y, z, dx, dy, dz, gx, gy, gz; uint32_t idx0, voxoff; };
-#define VRT_AO_SLOT 3328
+#define VRT_AO_SLOT 3584   // (dense scenes: 11 rows of 256 B + two rows of counters; brick scenes: 12 + 2)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- DF, hand-written look-up loop (primary rays of the primary-only kernel) ----------------------------------------------
@@ -2194,9 +2194,101 @@ __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f
     }
     finish(s, material, s.mask, (CNT && v.count_lookups != 0u) ? lk_bytes : fetches, r);
 }
+
+// ---- the same pool for brick scenes (df_ao_pool_loop's scheme in the generic loop) ---------------------------------------------
+// A ray of the pool: 12 dwords (sideDist, deltaDist, 1 / delta with its sign, mapPos), column k at row q: q * 256 + k * 4; the two rows
+// of counters behind them (3072: rays of the column's pixel that found a solid voxel; 3328, CNT: what the count planes report).
+struct BrickAoLane { DdaState s; float gx, gy, gz; uint32_t i, owner; bool live; };
+__device__ __forceinline__ void brick_ao_rest(BrickAoLane& l)
+{
+    l.s.sdx = l.s.sdy = l.s.sdz = 0.0f; l.s.dx = l.s.dy = l.s.dz = 0.0f; l.s.mx = l.s.my = l.s.mz = 0; l.s.sx = l.s.sy = l.s.sz = 0;
+    l.gx = l.gy = l.gz = 0.0f; l.i = 0u; l.owner = 0u; l.live = false;
+}
+// the lane's pixel's next AO ray into column `col`
+__device__ __forceinline__ void brick_ao_store(const VolumeView& v, uint32_t ldsw, uint32_t col, f3 start, f3 dir)
+{
+    DdaState s;
+    dda_entry(v, start, dir, s);
+    dda_rest(dir, s);
+    const float kInf = u2f(0x7F800000u);
+    __attribute__((address_space(3))) uint32_t* p = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + col * 4u);
+    p[0 * 64] = f2u(s.sdx); p[1 * 64] = f2u(s.sdy); p[2 * 64] = f2u(s.sdz);
+    p[3 * 64] = f2u(s.dx); p[4 * 64] = f2u(s.dy); p[5 * 64] = f2u(s.dz);
+    p[6 * 64] = f2u(s.dx < kInf ? dir.x : 0.0f); p[7 * 64] = f2u(s.dy < kInf ? dir.y : 0.0f); p[8 * 64] = f2u(s.dz < kInf ? dir.z : 0.0f);
+    p[9 * 64] = (uint32_t)s.mx; p[10 * 64] = (uint32_t)s.my; p[11 * 64] = (uint32_t)s.mz;
+}
+// One call: `count` rays wait in the pool, `next` of them are taken (in / out); more: come back when the pool is empty and a lane
+// rests.  Every lane spends its ray's own clearance, at most VRT_OWN_CAP_BRICK iterations per look (trace_brick_own).
+template <bool CNT>
+__device__ __forceinline__ void brick_ao_pool(const VolumeView& v, BrickAoLane& l, uint32_t ldsw, uint32_t count, bool more, uint32_t& next,
+                                              uint32_t maxSteps, uint32_t& looks)
+{
+    __attribute__((address_space(3))) uint32_t* pool = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)ldsw;
+    for (;;) {
+        uint32_t own = 0u;
+        if (l.live) {
+            bool ended = false, solid = false;
+            uint32_t fet = 0u;
+            if (l.i >= maxSteps) { ended = true; fet = l.i; }
+            else {
+                const uint32_t oct = (uint32_t)(l.s.sx > 0) | ((uint32_t)(l.s.sy > 0) << 1) | ((uint32_t)(l.s.sz > 0) << 2);
+                uint32_t m = 0u;
+                const uint32_t clear = brick_clear(v, l.s.mx, l.s.my, l.s.mz, oct, l.s.sx, l.s.sy, l.s.sz, m, CNT ? &looks : nullptr);
+                if (clear == 0u) {
+                    ended = true;
+                    solid = !oob(v, l.s.mx, l.s.my, l.s.mz) && m != 0u;
+                    fet = solid ? l.i + 1u : l.i;
+                } else if (clear >= maxSteps - l.i) { ended = true; fet = v.count_marched ? l.i : maxSteps; }
+                else own = clear < (uint32_t)VRT_OWN_CAP_BRICK ? clear : (uint32_t)VRT_OWN_CAP_BRICK;
+            }
+            if (ended) {
+                if (solid) __hip_atomic_fetch_add(pool + 12 * 64 + l.owner, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (CNT) __hip_atomic_fetch_add(pool + 13 * 64 + l.owner, fet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                l.live = false;
+            }
+        }
+        // lanes without a ray take the next ones of the pool: the wave's counter + the lane's rank among those asking
+        const uint64_t asking = __ballot(!l.live);
+        if (!l.live) {
+            const uint32_t slot = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(asking >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)asking, 0u));
+            if (slot < count) {
+                __attribute__((address_space(3))) uint32_t* p = pool + slot;
+                l.s.sdx = u2f(p[0 * 64]); l.s.sdy = u2f(p[1 * 64]); l.s.sdz = u2f(p[2 * 64]);
+                l.s.dx = u2f(p[3 * 64]); l.s.dy = u2f(p[4 * 64]); l.s.dz = u2f(p[5 * 64]);
+                l.gx = u2f(p[6 * 64]); l.gy = u2f(p[7 * 64]); l.gz = u2f(p[8 * 64]);
+                l.s.mx = (int)p[9 * 64]; l.s.my = (int)p[10 * 64]; l.s.mz = (int)p[11 * 64];
+                // rayStep from the direction's signs (an axis the ray cannot step along has g = 0: the step is never taken)
+                l.s.sx = l.gx > 0.0f ? 1 : (l.gx < 0.0f ? -1 : 0); l.s.sy = l.gy > 0.0f ? 1 : (l.gy < 0.0f ? -1 : 0); l.s.sz = l.gz > 0.0f ? 1 : (l.gz < 0.0f ? -1 : 0);
+                l.i = 0u; l.owner = slot;
+                // (a ray that starts outside the volume and misses it leaves in iteration 0, without a look: a miss with no fetches)
+                l.live = !oob(v, l.s.mx, l.s.my, l.s.mz);
+            }
+        }
+        const uint32_t taken = next + (uint32_t)__builtin_popcountll(asking);
+        next = taken < count ? taken : count;
+        const uint64_t live = __ballot(l.live);
+        if (next >= count && more && __ballot(!l.live) != 0ull) return;      // the pool wants refilling
+        if (live == 0ull) return;
+        if (__ballot(own != 0u) == 0ull) continue;                          // (only rays just taken up: their first look)
+        const float ox = l.s.sdx, oy = l.s.sdy, oz = l.s.sdz;
+        asm volatile("" : "+v"(l.s.dx), "+v"(l.s.dy), "+v"(l.s.dz));
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)VRT_OWN_CAP_BRICK; j++) {
+            const uint64_t mk = __ballot(own > j);
+            if (mk == 0ull) break;
+            dda_advance_live(l.s, mk);
+        }
+        l.s.mx += steps_signed(l.s.sdx - ox, l.gx); l.s.my += steps_signed(l.s.sdy - oy, l.gy); l.s.mz += steps_signed(l.s.sdz - oz, l.gz);
+        l.i += own;
+    }
+}
 #else
 template <class STATS, bool CNT = false>
 VRT_HD void trace_brick_own(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
+struct BrickAoLane { DdaState s; float gx, gy, gz; uint32_t i, owner; bool live; };
+VRT_HD void brick_ao_rest(BrickAoLane&) {}
+VRT_HD void brick_ao_store(const VolumeView&, uint32_t, uint32_t, f3, f3) {}
+template <bool CNT> VRT_HD void brick_ao_pool(const VolumeView&, BrickAoLane&, uint32_t, uint32_t, bool, uint32_t&, uint32_t, uint32_t&) {}
 #endif
 
 // DENSE: one R8 fetch per iteration.  Straight-line body with a single exit (out of budget, out of bounds or
