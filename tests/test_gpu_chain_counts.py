@@ -127,7 +127,8 @@ def test_counting_twins(vrt, oracle, engine):
             lk = looks["steps_total"].astype(np.int64)
             rays = twin["rays_total"].astype(np.int64)
             traced = b > 0
-            assert (lk[traced] >= 1).all() and (lk <= 3 * (np.maximum(a, b) + 2 * rays)).all(), (name, pos, "look-ups: at least one per traced pixel, at most three bytes per iteration + id")
+            # (an AO ray's look-ups are counted by the lane that makes them -- the rays come from the wave's pool -- so only sums are bounded)
+            assert (lk[traced] >= 1).all() and lk.sum() <= 3 * (np.maximum(a, b).sum() + 2 * rays.sum()), (name, pos, "look-ups: at least one per traced pixel, at most three bytes per iteration + id")
             if not ties:
                 assert lk.sum() < b.sum(), (name, pos, "the clearance runs are what keeps the march from asking per iteration")
     sc.destroy()

@@ -586,9 +586,13 @@ __device__ __forceinline__ f3 primary_normalize(const f3 v)
 // one after the other; the packed bounce chain (color_main_ray_packed) runs the first half on the way out and the second on the
 // way back.
 // SEC = false: the host has established ao_samples == 0 and shadows == 0 (K1 MODE 1), so neither loop is compiled in.
+// active: the lane has a hit whose secondary rays are wanted.  Where the AO rays go through the wave's pool the function must be reached
+// by the wave's other lanes as well (wave-uniform control flow at the call site): a lane without a hit of its own has no rays in
+// the pool but takes rays from it like everybody else -- the pixels of a block's silhouette, and the few metallic pixels of a bounce,
+// get the whole wave's help.  (Called from divergent code the pool simply serves the lanes that are there.)
 template <int TRAV, class Occ, bool SEC = true>
 __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ occ, PixCtx& c, const f3 pos, const f3 normal, uint32_t depth,
-                                               float& ambient, uint32_t& ao_hits, bool& shadowed)
+                                               float& ambient, uint32_t& ao_hits, bool& shadowed, const bool active = true)
 {
     const DevScene& s = P.sc;
     const vrt_settings& st = P.st;
@@ -602,28 +606,32 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
         // to the column's counter; which lane traces a ray changes nothing about what the ray finds
         constexpr bool kCnt = TRAV == VRT_TRAVERSAL_DF_FAST_CNT;
         const uint32_t ldsw = c.ldsw;
-        const uint64_t act = __ballot(true);
+        const uint64_t act = __ballot(active);
         const uint32_t col = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
         const uint32_t nact = (uint32_t)__builtin_popcountll(act);
         __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 2816u + col * 4u);
-        cnt[0] = 0u;
-        if (kCnt) cnt[64] = 0u;
+        if (active) { cnt[0] = 0u; if (kCnt) cnt[64] = 0u; }
         AoLane lane;
         ao_lane_rest(s.vol, lane);
         uint32_t next = 0u, looks = 0u;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
-            f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
-            f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
-            f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
-            AoRay a;
-            ao_ray_setup(s.vol, o, dir, a);
-            ao_ray_store(ldsw, col, a);
+            if (active) {
+                f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
+                f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
+                f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
+                AoRay a;
+                ao_ray_setup(s.vol, o, dir, a);
+                ao_ray_store(ldsw, col, a);
+            }
             next = 0u;
             trace_ao_pool<kCnt>(s.vol, lane, ldsw, nact, i + 1u < st.ao_samples ? 1u : 0u, next, st.ao_steps, looks);
         }
-        ao_hits = cnt[0];
-        c.rays += st.ao_samples;
-        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : cnt[64];
+        if (active) {
+            ao_hits = cnt[0];
+            c.rays += st.ao_samples;
+        }
+        // (look-ups are counted by the lane that makes them, iterations for the pixel the ray belongs to)
+        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : (active ? cnt[64] : 0u);
         // calcAmbient's sum (frag:219-222): one addition of 1 / aoSamples per ray that hit -- the value depends on their number only
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t q = 0; q < ao_hits; q++) ambient += sample_frac;
@@ -631,29 +639,32 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
         // brick scenes: the same pool in the generic loop (brick_ao_pool)
         constexpr bool kCnt = TRAV == VRT_TRAVERSAL_BRICK_CNT;
         const uint32_t ldsw = c.ldsw;
-        const uint64_t act = __ballot(true);
+        const uint64_t act = __ballot(active);
         const uint32_t col = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
         const uint32_t nact = (uint32_t)__builtin_popcountll(act);
         __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 3072u + col * 4u);
-        cnt[0] = 0u;
-        if (kCnt) cnt[64] = 0u;
+        if (active) { cnt[0] = 0u; if (kCnt) cnt[64] = 0u; }
         BrickAoLane lane;
         brick_ao_rest(lane);
         uint32_t next = 0u, looks = 0u;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
-            f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
-            f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
-            f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
-            brick_ao_store(s.vol, ldsw, col, o, dir);
+            if (active) {
+                f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
+                f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
+                f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
+                brick_ao_store(s.vol, ldsw, col, o, dir);
+            }
             next = 0u;
             brick_ao_pool<kCnt>(s.vol, lane, ldsw, nact, i + 1u < st.ao_samples, next, st.ao_steps, looks);
         }
-        ao_hits = cnt[0];
-        c.rays += st.ao_samples;
-        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : cnt[64];
+        if (active) {
+            ao_hits = cnt[0];
+            c.rays += st.ao_samples;
+        }
+        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : (active ? cnt[64] : 0u);
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t q = 0; q < ao_hits; q++) ambient += sample_frac;
-    } else {
+    } else if (active) {
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
             f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
@@ -669,7 +680,7 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
         }
     }
     shadowed = false;
-    if (SEC && st.shadows) {
+    if (SEC && st.shadows && active) {
         f3 L = mk3(st.light_dir[0], st.light_dir[1], st.light_dir[2]);
         f3 o = mk3(pos.x + normal.x * 0.01f, pos.y + normal.y * 0.01f, pos.z + normal.z * 0.01f);
         RayInt r;
@@ -704,14 +715,16 @@ __device__ __forceinline__ f3 shade_eval(const GeomParams& P, uint32_t material,
     return out;
 }
 
+// active = false: the lane has nothing to shade and is here for the others' AO rays (secondary_rays); its result is not used
 template <int TRAV, class Occ, bool SEC = true>
 __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit,
-                        f3 reflection, uint32_t depth)
+                        f3 reflection, uint32_t depth, const bool active = true)
 {
     const DevScene& s = P.sc;
-    if (hit.material == 0) return sky_color(s, hit.dir);
     float ambient; uint32_t ao_hits; bool shadowed;
-    secondary_rays<TRAV, Occ, SEC>(P, occ, c, hit.pos, hit.normal, depth, ambient, ao_hits, shadowed);
+    secondary_rays<TRAV, Occ, SEC>(P, occ, c, hit.pos, hit.normal, depth, ambient, ao_hits, shadowed, active && hit.material != 0);
+    if (!active) return mk3(0.0f, 0.0f, 0.0f);
+    if (hit.material == 0) return sky_color(s, hit.dir);
     // skyColor(hit.normal): the normal is one of 26 vectors, whose sky texels the scene holds in a table (computed by this very
     // function, k_sky_normals); any other normal is looked up here
     f3 sky;
@@ -731,12 +744,12 @@ __device__ f3 color_hit(const GeomParams& P, const Occ occ, PixCtx& c, const Ray
 // a metallic material): the loop and its stack of hits -- 352 bytes of scratch per lane, which every wave of the kernel is
 // given whether it bounces or not -- are compiled out
 template <int TRAV, class Occ, bool BOUNCE = true>
-__device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit)
+__device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit, const bool active = true)
 {
     const DevScene& s = P.sc;
     const vrt_settings& st = P.st;
     f3 reflection = mk3(0.0f, 0.0f, 0.0f);
-    if (BOUNCE && s.palette[hit.material].metallic > 0.0f && st.max_bounces > 0) {
+    if (BOUNCE && active && s.palette[hit.material].metallic > 0.0f && st.max_bounces > 0) {
         RayHit bounces[VRT_MAX_BOUNCES];
         RayHit last = hit;
         int last_idx = -1;
@@ -758,7 +771,7 @@ __device__ f3 color_main_ray(const GeomParams& P, const Occ occ, PixCtx& c, cons
             reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
         }
     }
-    return color_hit<TRAV>(P, occ, c, hit, reflection, 0);
+    return color_hit<TRAV>(P, occ, c, hit, reflection, 0, active);        // (wave-uniform again: the lanes without a hit help with the AO rays)
 }
 
 // colorMainRay with the bounce chain as ONE WORD per hit instead of a stack of RayHits (44 B each: 352 B of scratch per lane for
@@ -800,7 +813,7 @@ __device__ __forceinline__ f3 chain_shade(const GeomParams& P, uint32_t code, f3
 
 // NBT: the most bounces the launch can ask for (the chain's words are registers: 2, 5 or VRT_MAX_BOUNCES + 1 of them)
 template <int TRAV, class Occ, int NBT>
-__device__ f3 color_main_ray_packed(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit)
+__device__ f3 color_main_ray_packed(const GeomParams& P, const Occ occ, PixCtx& c, const RayHit& hit, const bool is_hit = true)
 {
     const DevScene& s = P.sc;
     const vrt_settings& st = P.st;
@@ -812,31 +825,41 @@ __device__ f3 color_main_ray_packed(const GeomParams& P, const Occ occ, PixCtx& 
     RayHit cur = hit;
     int last = 0;                                              // the chain's last entry that is shaded: 0 = the primary hit alone
     uint32_t spec_fetches = 0u, spec_rays = 0u;
-    for (int k = 0;; k++) {
+    // The loop over the chain's entries is WAVE-UNIFORM: a lane whose chain has ended (or that never had a hit) stays in it for as long
+    // as some lane's chain goes on, and takes AO rays from the pool like the others (secondary_rays) -- the few metallic pixels of a
+    // bounce get the whole wave's help.  Everything else a lane does here is under `on`: its own chain is still being followed.
+    bool on = is_hit;
+    for (int k = 0; __ballot(on) != 0ull; k++) {
         // the secondary rays of entry k (a hit: the primary, or a bounce that found something)
         float ambient; uint32_t ao_hits; bool shadowed;
         const uint32_t f0 = c.fetches, r0 = c.rays;
-        secondary_rays<TRAV, Occ, true>(P, occ, c, cur.pos, cur.normal, k > 0 ? (uint32_t)(k - 1) : 0u, ambient, ao_hits, shadowed);
-        codes[k] = chain_pack(cur.material, cur.normal, ao_hits, shadowed);
-        last = k;
-        const bool metal = s.palette[cur.material].metallic > 0.0f;
-        if (!metal) break;                                     // (k = 0: no chain at all; k > 0: the chain ends on a hit that does not reflect)
-        if (k > 0) { if (VRT_COUNTS(TRAV)) spec_fetches += c.fetches - f0; spec_rays += c.rays - r0; }    // a metallic bounce: shaded only if the chain ends
-        if (k >= nb) { last = -1; break; }                     // max_bounces metallic bounces (or max_bounces == 0): nothing on the chain is shaded
-        float d2 = 2.0f * dot3(cur.normal, cur.dir);
-        f3 rdir = mk3(cur.dir.x - d2 * cur.normal.x, cur.dir.y - d2 * cur.normal.y, cur.dir.z - d2 * cur.normal.z);
-        f3 o = mk3(cur.pos.x + cur.normal.x * 0.01f, cur.pos.y + cur.normal.y * 0.01f, cur.pos.z + cur.normal.z * 0.01f);
-        RayHit rh; RayInt ri;
-        trace_ray<TRAV, Occ, false, true>(s, occ, o, rdir, st.max_steps, rh, ri);
-        if (VRT_COUNTS(TRAV)) c.fetches += ri.fetches;
-        c.rays++;
-        if (rh.material == 0u) {                               // the chain ends in the sky: colorHit of a miss is skyColor(dir)
-            const f3 col = sky_color(s, rh.dir);
-            reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
-            break;
+        secondary_rays<TRAV, Occ, true>(P, occ, c, cur.pos, cur.normal, k > 0 ? (uint32_t)(k - 1) : 0u, ambient, ao_hits, shadowed, on);
+        if (on) {
+            codes[k] = chain_pack(cur.material, cur.normal, ao_hits, shadowed);
+            last = k;
+            const bool metal = s.palette[cur.material].metallic > 0.0f;
+            if (!metal) on = false;                            // (k = 0: no chain at all; k > 0: the chain ends on a hit that does not reflect)
+            else {
+                if (k > 0) { if (VRT_COUNTS(TRAV)) spec_fetches += c.fetches - f0; spec_rays += c.rays - r0; }    // a metallic bounce: shaded only if the chain ends
+                if (k >= nb) { last = -1; on = false; }        // max_bounces metallic bounces (or max_bounces == 0): nothing on the chain is shaded
+            }
         }
-        cur = rh;
+        if (on) {
+            float d2 = 2.0f * dot3(cur.normal, cur.dir);
+            f3 rdir = mk3(cur.dir.x - d2 * cur.normal.x, cur.dir.y - d2 * cur.normal.y, cur.dir.z - d2 * cur.normal.z);
+            f3 o = mk3(cur.pos.x + cur.normal.x * 0.01f, cur.pos.y + cur.normal.y * 0.01f, cur.pos.z + cur.normal.z * 0.01f);
+            RayHit rh; RayInt ri;
+            trace_ray<TRAV, Occ, false, true>(s, occ, o, rdir, st.max_steps, rh, ri);
+            if (VRT_COUNTS(TRAV)) c.fetches += ri.fetches;
+            c.rays++;
+            if (rh.material == 0u) {                           // the chain ends in the sky: colorHit of a miss is skyColor(dir)
+                const f3 col = sky_color(s, rh.dir);
+                reflection = mk3(reflection.x + col.x, reflection.y + col.y, reflection.z + col.z);
+                on = false;
+            } else cur = rh;
+        }
     }
+    if (!is_hit) return mk3(0.0f, 0.0f, 0.0f);
     if (last < 0) {
         // frag:281-303 with lastIdx = -1: the bounces' secondary rays were traced for nothing -- the reference never traces them
         if (VRT_COUNTS(TRAV)) c.fetches -= spec_fetches;
@@ -1339,13 +1362,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((MODE == 4
     }
     if (MODE != 0) {                                           // 1: primary only; 2: megakernel; 4: megakernel, nothing can bounce
         f3 col;
-        if (hit) {
+        if (MODE >= 5) {
+            // The packed chain is wave-uniform: in a wave with a hit EVERY lane goes through it, the lanes that missed (and those whose chain
+            // has ended) for the AO rays' sake -- they draw on the wave's pool like the others (secondary_rays); what they return is not
+            // used.  (The other forms keep the divergent call: with helpers at the primary hit alone the megakernel without its bounce
+            // loop needs 67 VGPRs instead of 64 and the reference defaults measured 132.8 against 128 us, config 5 3.32 against 3.07 ms.)
             PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame);
             c.ldsw = (uint32_t)(uintptr_t)(lds_u64_ptr)lds_occ + (uint32_t)wave * (uint32_t)VRT_AO_SLOT;   // (the hand-written loop's kernels are launched with a pool per wave)
+            f3 colh = mk3(0.0f, 0.0f, 0.0f);
+            if (__ballot(hit) != 0ull) colh = color_main_ray_packed<TRAV, OccT<kLds>, (MODE == 5 ? 2 : (MODE == 6 ? 5 : VRT_MAX_BOUNCES))>(P, occ, c, h, hit);
+            if (hit) {
+                col = colh;
+                if (VRT_COUNTS(TRAV) && steps_total && !(P.st.flags & 3u)) steps_total[i] = r.fetches + c.fetches;
+                if (rays_total && !(P.st.flags & 3u)) rays_total[i] = 1u + c.rays;
+            } else {
+                col = sky_color(s, dir);
+                // (VRT_FLAG_LOOKUP_COUNTS: the bytes a lane asked for while it helped with the others' AO rays belong to the frame's sum)
+                if (VRT_COUNTS(TRAV) && steps_total && P.sc.vol.count_lookups != 0u && !(P.st.flags & 3u)) steps_total[i] = r.fetches + c.fetches;
+            }
+        } else if (hit) {
+            PixCtx c; c.px = px; c.py = py; c.fetches = 0; c.rays = 0; c.pc = SlotOf<TABLE>::push(P, frame);
+            c.ldsw = (uint32_t)(uintptr_t)(lds_u64_ptr)lds_occ + (uint32_t)wave * (uint32_t)VRT_AO_SLOT;
             if (MODE == 1) col = color_hit<TRAV, OccT<kLds>, false>(P, occ, c, h, mk3(0.0f, 0.0f, 0.0f), 0);   // ambient = 1, unshadowed, no reflection
             else {
-                if (MODE >= 5) col = color_main_ray_packed<TRAV, OccT<kLds>, (MODE == 5 ? 2 : (MODE == 6 ? 5 : VRT_MAX_BOUNCES))>(P, occ, c, h);
-                else col = color_main_ray<TRAV, OccT<kLds>, MODE != 4>(P, occ, c, h);
+                col = color_main_ray<TRAV, OccT<kLds>, MODE != 4>(P, occ, c, h);
                 if (VRT_COUNTS(TRAV) && steps_total && !(P.st.flags & 3u)) steps_total[i] = r.fetches + c.fetches;
                 if (rays_total && !(P.st.flags & 3u)) rays_total[i] = 1u + c.rays;
             }
