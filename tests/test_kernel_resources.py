@@ -26,3 +26,20 @@ def test_product_kernels_stay_inside_their_register_budgets():
     worse[name]["TotalSGPRs"] = 81
     bad2, _ = check_resources.check(worse)
     assert any(frag in b and "SGPRs" in b for b in bad2)
+
+
+def test_assembly_blocks_write_only_what_they_declare():
+    """tools/check_asm_clobbers.py on the preprocessed device source: literal registers of every hand-written block are in its
+    clobber list, written operands are output operands -- and the lint does find a block that breaks either rule"""
+    import check_asm_clobbers as lint
+    stmts = lint.asm_statements(lint.preprocessed())
+    bad, blocks = lint.lint(stmts)
+    assert blocks >= 10, blocks                      # the look-up loops and their counting twins, the DPP reductions, the runs
+    assert not bad, bad[:5]
+    good = ('asm volatile("s_mov_b64 s[68:69], exec\\n\\t" "v_mov_b32 v53, %[a]\\n\\t" "v_add_u32 %[o], v53, %[a]\\n\\t" "s_nop 0\\n\\t" "s_nop 0\\n\\t" "s_nop 0\\n\\t"'
+            ' "s_nop 0\\n\\t" "s_nop 0\\n\\t" "s_mov_b64 exec, s[68:69]\\n\\t" : [o] "=v"(o) : [a] "v"(a) : "v53", "s68", "s69");')
+    assert lint.lint(lint.asm_statements(good)) == ([], 1)
+    undeclared = good.replace('"v53", "s68", "s69"', '"s68", "s69"')
+    assert any("v53" in b for b in lint.lint(lint.asm_statements(undeclared))[0])
+    writes_input = good.replace("v_add_u32 %[o], v53, %[a]", "v_add_u32 %[a], v53, %[a]")
+    assert any("INPUT operand" in b for b in lint.lint(lint.asm_statements(writes_input))[0])

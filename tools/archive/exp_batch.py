@@ -1,6 +1,6 @@
 """K1 time per frame as a function of the frames per launch (vrt_render_geometry_batch)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes as C
 import voxel_raytracing_amd as vrt
 res = (1920, 1080)

@@ -1,6 +1,6 @@
 """Ad-hoc: config 3 (shadow ray) frames for a --pmc SQ_INSTS_VALU run."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,7 +1,7 @@
 """BASELINE configs[4] (2048^3 sparse-brick scene, 3840x2160, max_steps 6144, 4 bounces, AO 4) on one GPU: geometry ms per frame.
 python tools/exp_cfg5.py [name=value ...] [--reps 7]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 args = sys.argv[1:]

@@ -1,7 +1,7 @@
 """Look-up statistics of config 5's primary rays (library built with -DVRT_TRACE_COUNTERS: make -C csrc variant NAME=cnt
 EXTRA=-DVRT_TRACE_COUNTERS; VRT_LIB=.../libvrt_hip_cnt.so)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes as C
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

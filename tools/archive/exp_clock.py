@@ -1,6 +1,6 @@
 """Ad-hoc: does K1 get faster when the GPU is kept busy (DVFS)?  Launch N frames back-to-back, time each with events."""
 import sys, os, time, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,6 +1,6 @@
 """Ad-hoc: stage timings at 1080p on the treehouse stand-in for BASELINE configs 2/3 and the reference defaults."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,7 +1,7 @@
 """Exact per-frame work counts of K1/DF on the bench frame (needs the counters variant of the library:
 make -C voxel-raytracing_amd/csrc variant NAME=cnt EXTRA=-DVRT_TRACE_COUNTERS; VRT_LIB=.../libvrt_hip_cnt.so)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, ctypes as C
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,6 +1,6 @@
 """K1 / geometry time with and without one development flag of the library: python tools/exp_flag.py FLAG"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes as C
 import voxel_raytracing_amd as vrt
 FLAG = int(sys.argv[1])

@@ -1,6 +1,6 @@
 """Ad-hoc experiment: K1 time vs step budget / view axis / resolution (diagnosing the latency floor)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 

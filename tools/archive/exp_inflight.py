@@ -1,6 +1,6 @@
 """Throughput of K1 with 1, 2 and 3 frames in flight (one context + stream + G-buffer per frame slot, one shared scene)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes as C
 import voxel_raytracing_amd as vrt
 res = (1920, 1080)

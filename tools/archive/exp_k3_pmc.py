@@ -1,6 +1,6 @@
 """Ad-hoc: ten frames of config 3's two denoiser passes, exact and VRT_DENOISE_FAST, for a --pmc pass over the K3 kernels."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,7 +1,7 @@
 """Ad-hoc: config 3's denoiser passes at 1080p -- the exact kernels, the verified pair, VRT_DENOISE_FAST -- timed by the
 context's events over single calls (ms per vrt_denoise call; pass 0 alone subtracted out with iterations = 1)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0); eng.set_option("denoise_count", int(os.environ.get("COUNT", "0")))
@@ -12,7 +12,7 @@ st = vrt.VoxelRenderSettings(targetResolution=res)
 st.fsrSetttings.enable = False
 st.occlusionSettings.numSamples = int(os.environ.get("AO", "0"))
 stage = vrt.GeometryStage(eng, st, sc)
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from helpers import camera_push
 gb = stage.record(camera_push(vrt, (256, 256, 256), res)); eng.synchronize()
 def run(iters, mode, verified):

@@ -3,7 +3,7 @@ single 256-slot launch, the unpack of 256 (source, frame) pairs, and the rank's 
 strips of the other sources are taken from this rank's own send buffer, which is what they would send for vrank = source
 rotation... only the self-sent block is checked)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 res = (1920, 1080)

@@ -1,7 +1,7 @@
 """Ad-hoc: open-cell termination (fields with 0 where a ray's octant is empty to the volume's corner) against fields without:
 planes identical?  stage timings at 1080p on the treehouse stand-in."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes as C
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,6 +1,6 @@
 """Ad-hoc: K1 time with the traversal budget forced to 1 (ray gen + setup + epilogue + stores only)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes as C
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,6 +1,6 @@
 """Rays traced per frame (primary + AO + shadow + bounce) and step counts for BASELINE configs 2 / 3 and the reference defaults."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

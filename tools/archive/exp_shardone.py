@@ -1,6 +1,6 @@
 """One configuration for counter collection: python tools/exp_shardone.py N  -- 64 frames per launch, rank 1 of N (N = 1: unsharded)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 N = int(sys.argv[1]); F = 64

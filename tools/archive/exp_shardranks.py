@@ -1,7 +1,7 @@
 """K1 time per step of EVERY rank of an N-GPU bench step (one GPU plays them one after the other), for contiguous bands and
 for 16-row strips: the step time of the job is the slowest rank's."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 res = (1920, 1080)

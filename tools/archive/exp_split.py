@@ -2,7 +2,7 @@
 configurations whose secondary rays are bound by the vector unit rather than by their chains of look-ups -- BASELINE configs[3]
 (Mandelbulb 512^3 at 3840x2160, 2 bounces, AO 4) and the reference defaults at 1080p.  Geometry ms per frame, one frame per launch."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1,6 +1,6 @@
 """K1 time per frame for launches of 8 (slots in the kernel arguments) and 16..64 frames (slot table in device memory)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import voxel_raytracing_amd as vrt
 res = (1920, 1080)

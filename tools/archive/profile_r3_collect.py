@@ -2,7 +2,7 @@
 summaries per kernel.  HBM bytes as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE from passes of their own, in KiB;
 FETCH_SIZE doubled on gfx950 for wide coalesced streams (both figures are kept: K1's reads are byte gathers)."""
 import collections, csv, glob, json, os, shutil, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bench import csrc_sha16
 R = "gpurun_out/r3prof"
 os.makedirs("profiles", exist_ok=True)

@@ -2,7 +2,7 @@
 denoiser passes: the verified pair, VRT_DENOISE_FAST, and the exact kernels computing every pixel), the reference defaults (AO 4, shadow, <= 5 bounces), and BASELINE configs[4]
 (2048^3 brick scene at 3840x2160) -- 10 frames each, the device idle between frames."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import voxel_raytracing_amd as vrt
 eng = vrt.Engine(0)

@@ -1380,7 +1380,9 @@ __device__ __forceinline__ void df_prim_loop(const uint8_t* base, int pw, int pw
 // per-lane iteration of a hit to remember -- a lane's own iteration count (fetches) is its i.
 // Same fp32 additions per lane, in the same order: bit-identical results.  Runs under the EXEC mask it is entered with.
 #ifndef VRT_OWN_CAP
-#define VRT_OWN_CAP 4                // iterations of its own a lane may take per look (df_any_loop; measured: DESIGN.md 5)
+#define VRT_OWN_CAP 6                // iterations of its own a lane may take per look.  Round 3 (df_any_loop, a ray per lane): 4.  With the wave's pool
+                                     // (df_ao_pool_loop) a lane that is done does not wait for the others, so longer stretches pay: reference defaults /
+                                     // Mandelbulb 4K at 3: 138 us / 1.09 ms, 4: 128 / 1.06, 6: 121 / 1.025, 8: 118 / 1.047, 12: 120 / 1.065, 16: 126 / 1.10
 #endif
 #ifndef VRT_THRESH_SPREAD
 #define VRT_THRESH_SPREAD 1          // brick_march_thresh: a lane's threshold run uses at most this many times the wave's smallest clearance (measured on config 5: 1 -> 3.38 ms, 2 -> 3.46, 4 -> 3.48, no cap -> 13 ms: the others wait for the lane that goes furthest)
