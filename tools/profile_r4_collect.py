@@ -130,7 +130,8 @@ if hb:
     lines.append(f"| K1 + tags HBM bytes per launch (guide rule / raw fetch) | {hb['total_guide_rule'] / 1e9:.3f} / {hb['total_raw_fetch'] / 1e9:.3f} GB | profiles/r04_k_primary_pmc.json | hbm_bytes_per_launch |")
     if v:
         lines.append(f"| K1 vector instructions per launch / per frame; issue time at 4 cycles | {v / 1e6:.1f} M / {v / fpl / 1e6:.2f} M; {v * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3:.3f} ms | profiles/r04_k_primary_pmc.json | counters.SQ_INSTS_VALU |")
-plain = {m.group(1): (float(m.group(2)), float(m.group(3))) for m in re.finditer(r"VARIANT (\S+) geometry=\d+ denoise_passes=\d+ geometry_us=([\d.]+) denoise_us=([-\d.]+)", open(f"{R}/cfg_plain.log").read())} if os.path.exists(f"{R}/cfg_plain.log") else {}
+plain = {m.group(1): (float(m.group(3)), float(m.group(4)) if int(m.group(2)) > 0 else -1.0)
+         for m in re.finditer(r"VARIANT (\S+) geometry=\d+ denoise_passes=(\d+) geometry_us=([\d.]+) denoise_us=([-\d.]+)", open(f"{R}/cfg_plain.log").read())} if os.path.exists(f"{R}/cfg_plain.log") else {}
 for tag in ("config3", "defaults", "mandelbulb", "brick"):
     d = per.get(tag)
     if not d:
@@ -156,3 +157,10 @@ if os.path.exists(f"{R}/cfg_plain.log"):
     shutil.copy(f"{R}/cfg_plain.log", "profiles/r04_configs_plain.log")
 open("profiles/r04_claims.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+# DESIGN.md 7 carries the same table between two markers: this script is the only writer of the numbers there
+if os.path.exists("DESIGN.md"):
+    d = open("DESIGN.md").read()
+    b, e = "<!-- r04_claims:begin -->", "<!-- r04_claims:end -->"
+    if b in d and e in d:
+        d = d[:d.index(b) + len(b)] + "\n" + "\n".join(lines[2:]) + "\n" + d[d.index(e):]
+        open("DESIGN.md", "w").write(d)
