@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -2 gpurun_out/bench_final.err
+timeout -k 10 1100 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+timeout -k 10 300 python3 tools/exp_r4_breakdown.py scenes=tm n=7 | grep -E "ao4 |full"

@@ -608,30 +608,54 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
         const uint32_t ldsw = c.ldsw;
         const uint64_t act = __ballot(active);
         const uint32_t col = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-        const uint32_t nact = (uint32_t)__builtin_popcountll(act);
-        __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 2816u + col * 4u);
+        __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 3072u + col * 4u);
         if (active) { cnt[0] = 0u; if (kCnt) cnt[64] = 0u; }
+        // the fields as the loops address them (offsets count from one slice in front of field 0)
+        const uint8_t* const fld = s.vol.df - (size_t)(s.vol.W + 2) * (size_t)(s.vol.H + 2);
         AoLane lane;
         ao_lane_rest(s.vol, lane);
-        uint32_t next = 0u, looks = 0u;
+        uint32_t next = 0u, looks = 0u, direct_hits = 0u, direct_fet = 0u;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
+            // The OWNER looks at its ray's first voxel itself -- every lane at once, where in the pool a ray's first look is a round of
+            // the loop like any other: a ray in the open (the clearance covers its budget) and a ray that starts on a 0 byte are
+            // decided here and never enter the pool; the others bring their first clearance with them and are marched from the round
+            // they are taken up in.  The rays that will creep (clearance 1 or 2) wait in FRONT of the pool: the longest rays of a
+            // sample start first, which is what the end of the AO phase waits for.
+            bool store = false;
+            uint32_t c0 = 0u;
+            AoRay a;
             if (active) {
                 f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
                 f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
                 f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
-                AoRay a;
                 ao_ray_setup(s.vol, o, dir, a);
-                ao_ray_store(ldsw, col, a);
+                c0 = fld[a.idx0];
+                if (kCnt) looks += 1u;
+                if (c0 == 0u) {                                // solid, border or open cell: the voxel id says which (frag:157 at iteration 0)
+                    const uint32_t id = fld[a.idx0 + a.voxoff];
+                    if (id != 0u) direct_hits++;
+                    if (kCnt) { looks += 1u; direct_fet += id != 0u ? 1u : 0u; }
+                } else if (c0 >= st.ao_steps) {                // nothing but empty voxels until the budget ends: a miss
+                    if (kCnt) direct_fet += s.vol.count_marched != 0u ? 0u : st.ao_steps;
+                } else store = true;
+            }
+            const bool creeps = store && c0 <= 2u;
+            const uint64_t mc = __ballot(creeps), mo = __ballot(store && !creeps);
+            const uint32_t nc = (uint32_t)__builtin_popcountll(mc);
+            if (store) {
+                const uint32_t slot = creeps ? __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, 0u))
+                                             : nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
+                ao_ray_store(ldsw, slot, a, col | (c0 << 8));
             }
             next = 0u;
-            trace_ao_pool<kCnt>(s.vol, lane, ldsw, nact, i + 1u < st.ao_samples ? 1u : 0u, next, st.ao_steps, looks);
+            trace_ao_pool<kCnt>(s.vol, lane, ldsw, nc + (uint32_t)__builtin_popcountll(mo), i + 1u < st.ao_samples ? 1u : 0u, next, st.ao_steps, looks);
         }
         if (active) {
-            ao_hits = cnt[0];
+            ao_hits = cnt[0] + direct_hits;
             c.rays += st.ao_samples;
         }
         // (look-ups are counted by the lane that makes them, iterations for the pixel the ray belongs to)
-        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : (active ? cnt[64] : 0u);
+        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : (active ? cnt[64] + direct_fet : 0u);
         // calcAmbient's sum (frag:219-222): one addition of 1 / aoSamples per ray that hit -- the value depends on their number only
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t q = 0; q < ao_hits; q++) ambient += sample_frac;

@@ -1518,9 +1518,10 @@ __device__ __forceinline__ void df_any_loop(const uint8_t* base, uint32_t maxSte
 // additions per ray in the same order, the iteration count of a ray its own -- which ray a lane works on changes no result.
 // A ray that never enters the volume is handed over with zero deltas and an index whose byte is 0 (the first byte of a field:
 // its border): it ends at its first look, as a miss, like any other ray ends.
-// LDS of a wave (VRT_AO_SLOT bytes at ldsw): the pool, dword q of the ray in column k at q * 256 + k * 4 (x y z dx dy dz gx gy gz idx0
-// voxoff); at 2816 one counter per column: rays of that column's pixel that found a solid voxel; at 3072 (CNT) what the count planes
-// report for them.  Column = rank of the pixel's lane among the lanes the AO phase runs under.
+// LDS of a wave (VRT_AO_SLOT bytes at ldsw): the pool, dword q of the ray in slot k at q * 256 + k * 4 (x y z dx dy dz gx gy gz idx0
+// voxoff tag; tag = the column of the ray's pixel | the clearance at its first voxel << 8); at 3072 one counter per COLUMN: rays of
+// that pixel that found a solid voxel; at 3328 (CNT) what the count planes report for them.  Column = rank of the pixel's lane
+// among the lanes the AO phase runs for; slot = where the ray waits (the owners put the rays that will creep in front).
 template <bool CNT>
 __device__ __forceinline__ void df_ao_pool_loop(const uint8_t* base, uint32_t maxSteps, int pw, int pwh, uint32_t sentinel,
                                                 uint32_t ldsw, uint32_t ldsh, uint32_t count, uint32_t more, uint32_t& next,
@@ -1613,7 +1614,7 @@ __device__ __forceinline__ void df_ao_pool_loop(const uint8_t* base, uint32_t ma
         "s_and_saveexec_b64 s[70:71], vcc\n\t" /* EXEC = asking and served; s[70:71] = asking */ \
         "s_cbranch_execz 126f\n\t" \
         "v_lshl_add_u32 v49, v48, 2, %[ldsw]\n\t" \
-        "v_mov_b32 %[own], v48\n\t" \
+        "ds_read_b32 v50, v49 offset:2816\n\t" /* the ray's pixel (its counters' column) and the clearance its owner read at its start */ \
         "ds_read_b32 %[x], v49\n\t" \
         "ds_read_b32 %[y], v49 offset:256\n\t" \
         "ds_read_b32 %[z], v49 offset:512\n\t" \
@@ -1626,8 +1627,10 @@ __device__ __forceinline__ void df_ao_pool_loop(const uint8_t* base, uint32_t ma
         "ds_read_b32 %[idx0], v49 offset:2304\n\t" \
         "ds_read_b32 %[voxoff], v49 offset:2560\n\t" \
         "v_mov_b32 v54, 0\n\t" \
-        "v_mov_b32 v52, 0xfe\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_and_b32 %[own], 0xff, v50\n\t" \
+        "v_lshrrev_b32 v52, 8, v50\n\t" /* (1 .. maxSteps - 1: the lane goes on to its iterations in this very round) */ \
+        "v_mov_b32 v53, %[idx0]\n\t" \
         "v_mul_legacy_f32 %[cx], %[x], %[gx]\n\t" /* c = -(side0 * g): where the ray stands is rint(side * g + c) steps from its start */ \
         "v_mul_legacy_f32 %[cy], %[y], %[gy]\n\t" \
         "v_mul_legacy_f32 %[cz], %[z], %[gz]\n\t" \
@@ -1816,14 +1819,15 @@ __device__ __forceinline__ void ao_ray_setup(const VolumeView& v, f3 start, f3 d
     a.voxoff = 8u * stride - (octoff - bias);
 }
 
-// a ray into column `col` of the wave's pool (ldsw: the byte address of the wave's LDS)
-__device__ __forceinline__ void ao_ray_store(uint32_t ldsw, uint32_t col, const AoRay& a)
+// a ray into column `col` of the wave's pool (ldsw: the byte address of the wave's LDS); tag: the column of its pixel's counters | the
+// clearance its owner read at its first voxel << 8
+__device__ __forceinline__ void ao_ray_store(uint32_t ldsw, uint32_t col, const AoRay& a, uint32_t tag)
 {
     __attribute__((address_space(3))) uint32_t* p = (__attribute__((address_space(3))) uint32_t*)(ldsw + col * 4u);
     p[0 * 64] = f2u(a.x); p[1 * 64] = f2u(a.y); p[2 * 64] = f2u(a.z);
     p[3 * 64] = f2u(a.dx); p[4 * 64] = f2u(a.dy); p[5 * 64] = f2u(a.dz);
     p[6 * 64] = f2u(a.gx); p[7 * 64] = f2u(a.gy); p[8 * 64] = f2u(a.gz);
-    p[9 * 64] = a.idx0; p[10 * 64] = a.voxoff;
+    p[9 * 64] = a.idx0; p[10 * 64] = a.voxoff; p[11 * 64] = tag;
 }
 
 // What a lane of the pool loop carries from one call to the next: the ray it is on (or the resting state it starts in)
@@ -1851,7 +1855,7 @@ __device__ __forceinline__ void trace_ao_pool(const VolumeView& v, AoLane& l, ui
     const uint32_t lw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ldsw);
     uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
     df_ao_pool_loop<CNT>(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)maxSteps), __builtin_amdgcn_readfirstlane(pw), __builtin_amdgcn_readfirstlane(pwh),
-                         (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), lw, lw + 2816u, (uint32_t)__builtin_amdgcn_readfirstlane((int)count),
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)sentinel), lw, lw + 3072u, (uint32_t)__builtin_amdgcn_readfirstlane((int)count),
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)more), nx,
                          l.x, l.y, l.z, l.dx, l.dy, l.dz, l.gx, l.gy, l.gz, l.cx, l.cy, l.cz, l.idx0, l.voxoff, l.state, l.owner,
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)v.count_marched), looks);
@@ -1862,7 +1866,7 @@ __device__ __forceinline__ void trace_ao_pool(const VolumeView& v, AoLane& l, ui
 template <class STATS, bool ANYHIT = false, bool PF = false, bool OWN = false, bool CNT = false>
 VRT_HD void trace_df_fast(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 VRT_HD void ao_ray_setup(const VolumeView&, f3, f3, AoRay&) {}
-VRT_HD void ao_ray_store(uint32_t, uint32_t, const AoRay&) {}
+VRT_HD void ao_ray_store(uint32_t, uint32_t, const AoRay&, uint32_t) {}
 struct AoLane { float x, y, z, dx, dy, dz, gx, gy, gz, cx, cy, cz; uint32_t idx0, voxoff, state, owner; };
 VRT_HD void ao_lane_rest(const VolumeView&, AoLane&) {}
 template <bool CNT> VRT_HD void trace_ao_pool(const VolumeView&, AoLane&, uint32_t, uint32_t, uint32_t, uint32_t&, uint32_t, uint32_t&) {}
