@@ -665,27 +665,47 @@ __device__ __forceinline__ void secondary_rays(const GeomParams& P, const Occ oc
         const uint32_t ldsw = c.ldsw;
         const uint64_t act = __ballot(active);
         const uint32_t col = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-        const uint32_t nact = (uint32_t)__builtin_popcountll(act);
-        __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 3072u + col * 4u);
+        __attribute__((address_space(3))) uint32_t* cnt = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + 3328u + col * 4u);
         if (active) { cnt[0] = 0u; if (kCnt) cnt[64] = 0u; }
         BrickAoLane lane;
         brick_ao_rest(lane);
-        uint32_t next = 0u, looks = 0u;
+        uint32_t next = 0u, looks = 0u, direct_hits = 0u, direct_fet = 0u;
         for (uint32_t i = 0; i < st.ao_samples; i++) {
+            // (the owner looks at its ray's first voxel itself, as on dense scenes: rays in the open, rays on a 0 byte and rays that never
+            // enter the volume are decided here; the rays that will creep wait in front of the pool)
+            bool store = false;
+            uint32_t c0 = 0u;
+            DdaState rs; float gx = 0.0f, gy = 0.0f, gz = 0.0f;
             if (active) {
                 f3 rd = random_dir(s, *c.pc, c, i + depth * st.ao_samples);
                 f3 dir = mk3(normal.x + rd.x, normal.y + rd.y, normal.z + rd.z);
                 f3 o = mk3(pos.x + dir.x * 0.01f, pos.y + dir.y * 0.01f, pos.z + dir.z * 0.01f);
-                brick_ao_store(s.vol, ldsw, col, o, dir);
+                brick_ao_setup(s.vol, o, dir, rs, gx, gy, gz);
+                if (!oob(s.vol, rs.mx, rs.my, rs.mz)) {          // (else: starts outside and misses the volume: leaves in iteration 0, no fetch)
+                    const uint32_t oct = (uint32_t)(rs.sx > 0) | ((uint32_t)(rs.sy > 0) << 1) | ((uint32_t)(rs.sz > 0) << 2);
+                    uint32_t m = 0u;
+                    c0 = brick_clear(s.vol, rs.mx, rs.my, rs.mz, oct, rs.sx, rs.sy, rs.sz, m, kCnt ? &looks : nullptr);
+                    if (c0 == 0u) { if (m != 0u) direct_hits++; if (kCnt) direct_fet += m != 0u ? 1u : 0u; }
+                    else if (c0 >= st.ao_steps) { if (kCnt) direct_fet += s.vol.count_marched != 0u ? 0u : st.ao_steps; }
+                    else store = true;
+                }
+            }
+            const bool creeps = store && c0 <= 2u;
+            const uint64_t mc = __ballot(creeps), mo = __ballot(store && !creeps);
+            const uint32_t nc = (uint32_t)__builtin_popcountll(mc);
+            if (store) {
+                const uint32_t slot = creeps ? __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, 0u))
+                                             : nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
+                brick_ao_store(ldsw, slot, rs, gx, gy, gz, col | (c0 << 8));
             }
             next = 0u;
-            brick_ao_pool<kCnt>(s.vol, lane, ldsw, nact, i + 1u < st.ao_samples, next, st.ao_steps, looks);
+            brick_ao_pool<kCnt>(s.vol, lane, ldsw, nc + (uint32_t)__builtin_popcountll(mo), i + 1u < st.ao_samples, next, st.ao_steps, looks);
         }
         if (active) {
-            ao_hits = cnt[0];
+            ao_hits = cnt[0] + direct_hits;
             c.rays += st.ao_samples;
         }
-        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : (active ? cnt[64] : 0u);
+        if (kCnt) c.fetches += s.vol.count_lookups != 0u ? looks : (active ? cnt[64] + direct_fet : 0u);
         float sample_frac = 1.0f / (float)st.ao_samples;
         for (uint32_t q = 0; q < ao_hits; q++) ambient += sample_frac;
     } else if (active) {

@@ -804,7 +804,7 @@ VRT_HD void trace_df_impl(const VolumeView& v, f3 start, f3 dir, uint32_t maxSte
 
 // an AO ray as df_ao_pool_loop takes it up, and the LDS bytes of a wave's pool (11 dwords x 64 columns) + its two rows of counters
 struct AoRay { float x, y, z, dx, dy, dz, gx, gy, gz; uint32_t idx0, voxoff; };
-#define VRT_AO_SLOT 3584   // (dense scenes: 11 rows of 256 B + two rows of counters; brick scenes: 12 + 2)
+#define VRT_AO_SLOT 3840   // (dense scenes: 12 rows of 256 B + two rows of counters; brick scenes: 13 + 2)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- DF, hand-written look-up loop (primary rays of the primary-only kernel) ----------------------------------------------
@@ -2202,26 +2202,31 @@ __device__ __forceinline__ void trace_brick_own(const VolumeView& v, f3 start, f
 }
 
 // ---- the same pool for brick scenes (df_ao_pool_loop's scheme in the generic loop) ---------------------------------------------
-// A ray of the pool: 12 dwords (sideDist, deltaDist, 1 / delta with its sign, mapPos), column k at row q: q * 256 + k * 4; the two rows
-// of counters behind them (3072: rays of the column's pixel that found a solid voxel; 3328, CNT: what the count planes report).
+// A ray of the pool: 13 dwords (sideDist, deltaDist, 1 / delta with its sign, mapPos, tag = column of its pixel | first clearance << 8), slot k
+// at row q: q * 256 + k * 4; the two rows of counters behind them (3328: rays of the column's pixel that found a solid voxel; 3584, CNT:
+// what the count planes report).
 struct BrickAoLane { DdaState s; float gx, gy, gz; uint32_t i, owner; bool live; };
 __device__ __forceinline__ void brick_ao_rest(BrickAoLane& l)
 {
     l.s.sdx = l.s.sdy = l.s.sdz = 0.0f; l.s.dx = l.s.dy = l.s.dz = 0.0f; l.s.mx = l.s.my = l.s.mz = 0; l.s.sx = l.s.sy = l.s.sz = 0;
     l.gx = l.gy = l.gz = 0.0f; l.i = 0u; l.owner = 0u; l.live = false;
 }
-// the lane's pixel's next AO ray into column `col`
-__device__ __forceinline__ void brick_ao_store(const VolumeView& v, uint32_t ldsw, uint32_t col, f3 start, f3 dir)
+// the set-up of the lane's pixel's next AO ray (frag:109-144) ...
+__device__ __forceinline__ void brick_ao_setup(const VolumeView& v, f3 start, f3 dir, DdaState& s, float& gx, float& gy, float& gz)
 {
-    DdaState s;
     dda_entry(v, start, dir, s);
     dda_rest(dir, s);
     const float kInf = u2f(0x7F800000u);
-    __attribute__((address_space(3))) uint32_t* p = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + col * 4u);
+    gx = s.dx < kInf ? dir.x : 0.0f; gy = s.dy < kInf ? dir.y : 0.0f; gz = s.dz < kInf ? dir.z : 0.0f;
+}
+// ... and the ray into slot `slot` of the pool; tag: the column of its pixel's counters | the clearance its owner read at its first voxel << 8
+__device__ __forceinline__ void brick_ao_store(uint32_t ldsw, uint32_t slot, const DdaState& s, float gx, float gy, float gz, uint32_t tag)
+{
+    __attribute__((address_space(3))) uint32_t* p = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ldsw + slot * 4u);
     p[0 * 64] = f2u(s.sdx); p[1 * 64] = f2u(s.sdy); p[2 * 64] = f2u(s.sdz);
     p[3 * 64] = f2u(s.dx); p[4 * 64] = f2u(s.dy); p[5 * 64] = f2u(s.dz);
-    p[6 * 64] = f2u(s.dx < kInf ? dir.x : 0.0f); p[7 * 64] = f2u(s.dy < kInf ? dir.y : 0.0f); p[8 * 64] = f2u(s.dz < kInf ? dir.z : 0.0f);
-    p[9 * 64] = (uint32_t)s.mx; p[10 * 64] = (uint32_t)s.my; p[11 * 64] = (uint32_t)s.mz;
+    p[6 * 64] = f2u(gx); p[7 * 64] = f2u(gy); p[8 * 64] = f2u(gz);
+    p[9 * 64] = (uint32_t)s.mx; p[10 * 64] = (uint32_t)s.my; p[11 * 64] = (uint32_t)s.mz; p[12 * 64] = tag;
 }
 // One call: `count` rays wait in the pool, `next` of them are taken (in / out); more: come back when the pool is empty and a lane
 // rests.  Every lane spends its ray's own clearance, at most VRT_OWN_CAP_BRICK iterations per look (trace_brick_own).
@@ -2248,8 +2253,8 @@ __device__ __forceinline__ void brick_ao_pool(const VolumeView& v, BrickAoLane& 
                 else own = clear < (uint32_t)VRT_OWN_CAP_BRICK ? clear : (uint32_t)VRT_OWN_CAP_BRICK;
             }
             if (ended) {
-                if (solid) __hip_atomic_fetch_add(pool + 12 * 64 + l.owner, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (CNT) __hip_atomic_fetch_add(pool + 13 * 64 + l.owner, fet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (solid) __hip_atomic_fetch_add(pool + 13 * 64 + l.owner, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (CNT) __hip_atomic_fetch_add(pool + 14 * 64 + l.owner, fet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 l.live = false;
             }
         }
@@ -2265,9 +2270,11 @@ __device__ __forceinline__ void brick_ao_pool(const VolumeView& v, BrickAoLane& 
                 l.s.mx = (int)p[9 * 64]; l.s.my = (int)p[10 * 64]; l.s.mz = (int)p[11 * 64];
                 // rayStep from the direction's signs (an axis the ray cannot step along has g = 0: the step is never taken)
                 l.s.sx = l.gx > 0.0f ? 1 : (l.gx < 0.0f ? -1 : 0); l.s.sy = l.gy > 0.0f ? 1 : (l.gy < 0.0f ? -1 : 0); l.s.sz = l.gz > 0.0f ? 1 : (l.gz < 0.0f ? -1 : 0);
-                l.i = 0u; l.owner = slot;
-                // (a ray that starts outside the volume and misses it leaves in iteration 0, without a look: a miss with no fetches)
-                l.live = !oob(v, l.s.mx, l.s.my, l.s.mz);
+                const uint32_t tag = p[12 * 64];
+                l.i = 0u; l.owner = tag & 0xFFu; l.live = true;
+                // (its owner read the clearance at its first voxel: 1 .. maxSteps - 1; the lane marches it in this very round)
+                const uint32_t c0 = tag >> 8;
+                own = c0 < (uint32_t)VRT_OWN_CAP_BRICK ? c0 : (uint32_t)VRT_OWN_CAP_BRICK;
             }
         }
         const uint32_t taken = next + (uint32_t)__builtin_popcountll(asking);
@@ -2293,7 +2300,8 @@ template <class STATS, bool CNT = false>
 VRT_HD void trace_brick_own(const VolumeView&, f3, f3, uint32_t, RayInt&, STATS&) {}
 struct BrickAoLane { DdaState s; float gx, gy, gz; uint32_t i, owner; bool live; };
 VRT_HD void brick_ao_rest(BrickAoLane&) {}
-VRT_HD void brick_ao_store(const VolumeView&, uint32_t, uint32_t, f3, f3) {}
+VRT_HD void brick_ao_setup(const VolumeView&, f3, f3, DdaState&, float&, float&, float&) {}
+VRT_HD void brick_ao_store(uint32_t, uint32_t, const DdaState&, float, float, float, uint32_t) {}
 template <bool CNT> VRT_HD void brick_ao_pool(const VolumeView&, BrickAoLane&, uint32_t, uint32_t, bool, uint32_t&, uint32_t, uint32_t&) {}
 #endif
 
