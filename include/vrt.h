@@ -149,8 +149,11 @@ int  vrt_ctx_set_stream(vrt_ctx* ctx, void* hip_stream);
 int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle(), engine.cpp:351 */
 /* Development switches of a context (no reference analogue; the reference's counterpart is recompiling a shader): each changes
  * speed only, never a result -- the tests render "the same frame without X" with them.  Name (default), who looks at it:
- *   every vrt_render_geometry* call:  "tile_tags" (1), "box_rect" (1), "fast_loop" (1), "thresh_runs" (1), "ao_batch" (1), "tags_async" (0: the tags of a launch on a stream of their own measured slower), "hit_table" (1),
- *                                     "no_bounce_kernel" (1), "packed_bounces" (1), "sky_fast" (1),
+ *   every vrt_render_geometry* call:  "tile_tags" (1), "box_rect" (1), "fast_loop" (1), "thresh_runs" (1), "hit_table" (1), "sky_fast" (1),
+ *                                     "no_bounce_kernel" (1), "ao_batch" (1: the AO rays of a wave from a pool in LDS every lane draws on),
+ *                                     "packed_bounces" (1: the bounce chain as one word per hit on dense scenes; 2: on brick scenes too,
+ *                                     where it measured slower; 0: the stack of hits), "tags_async" (0: the tile tags of a launch on a
+ *                                     stream of their own measured slower),
  *                                     "xcd_regions" (0 -- until round 3 VRT_XCD_REGIONS was on by default; as a three-dimensional grid the
  *                                     form ran 30.0 or 33.6 us per bench frame from one process to the next, so it is opt-in now)
  *   vrt_denoise:                      "denoise_packed" (1), "denoise_verified" (1), "denoise_th16" (0: the tolerance kernel's 64 x 16 tiles
