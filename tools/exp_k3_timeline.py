@@ -1,5 +1,5 @@
 """Where a weighted denoiser pass spends its 27 us (development build: make -C voxel-raytracing_amd/csrc variant NAME=k3st
-EXTRA=-DVRT_K3_STAMPS; VRT_LIB=.../libvrt_hip_k3st.so): every workgroup of k_denoise_ver leaves its start / ring filled / rows done /
+EXTRA=-DVRT_K3_STAMPS; VRT_LIB=.../libvrt_hip_k3st.so): every workgroup of k_denoise_ver / k_denoise_pair leaves its start / ring filled / rows done /
 end stamps (100 MHz) in the first words of the output image."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,9 @@ st.denoiserSettings.iterations = 2
 den = vrt.DenoiserStage(eng, st)
 for rep in range(4):
     out = den.record(gb.color, gb.normal, gb.position); eng.synchronize()
-n = 30 * 34
+gx = int(sys.argv[1]) if len(sys.argv) > 1 else 30          # strips and segments of the launch (k_denoise_ver: 30 x 34; k_denoise_pair at 1080p: 34 x 40)
+gy = int(sys.argv[2]) if len(sys.argv) > 2 else 34
+n = gx * gy
 w = out.cpu().numpy().view(np.uint32).reshape(-1)[: 4 * n].reshape(n, 4).astype(np.int64)
 t0 = w[:, 0].min()
 w = (w - t0) / 100.0                                       # us
@@ -27,13 +29,16 @@ for name, col in (("start", 0), ("ring filled", 1), ("rows done", 2), ("end", 3)
 print("prologue (ring filled - start): median %.1f max %.1f;  rows: median %.1f max %.1f;  tail: median %.1f max %.1f" % (
       np.median(w[:, 1] - w[:, 0]), (w[:, 1] - w[:, 0]).max(), np.median(w[:, 2] - w[:, 1]), (w[:, 2] - w[:, 1]).max(), np.median(w[:, 3] - w[:, 2]), (w[:, 3] - w[:, 2]).max()))
 
+tail = np.sort((w[:, 3] - w[:, 2])[(w[:, 3] - w[:, 2] >= 0) & (w[:, 3] - w[:, 2] < 100)]); m = len(tail)
+print("tail (end - rows done): 50%% %.1f 70%% %.1f 90%% %.1f 99%% %.1f max %.1f; over 1 us: %d of %d" % (tail[m // 2], tail[7 * m // 10], tail[9 * m // 10], tail[99 * m // 100], tail[-1], int((tail > 1.0).sum()), m))
+pro = np.sort((w[:, 1] - w[:, 0])[(w[:, 1] - w[:, 0] >= 0) & (w[:, 1] - w[:, 0] < 100)]); m = len(pro)
+print("ring fill (+ in-loop redo rounds of k_denoise_pair): 50%% %.1f 70%% %.1f 90%% %.1f 99%% %.1f max %.1f" % (pro[m // 2], pro[7 * m // 10], pro[9 * m // 10], pro[99 * m // 100], pro[-1]))
 ok = np.abs(w[:, 0] - np.median(w[:, 0])) < 2.0              # (stamps of a few workgroups are overwritten by pixels of the first rows)
 ok &= (w[:, 3] > w[:, 0]) & (w[:, 3] < w[:, 0] + 100)
 rows = w[:, 2] - w[:, 1]; life = w[:, 3] - w[:, 0]
-gx, gy = 30, n // 30
 ids = np.arange(n); bx, by = ids % gx, ids // gx
 print("usable", int(ok.sum()), "of", n)
 print("life by wg_id % 8 (XCD):", [round(float(np.median(life[ok & (ids % 8 == k)])), 1) for k in range(8)])
-print("life by segment row (0..33):", [round(float(np.median(life[ok & (by == k)])), 1) for k in range(gy)])
-print("life by strip (0..29):", [round(float(np.median(life[ok & (bx == k)])), 1) for k in range(gx)])
+print("life by segment row:", [round(float(np.median(life[ok & (by == k)])), 1) for k in range(gy)])
+print("life by strip:", [round(float(np.median(life[ok & (bx == k)])), 1) for k in range(gx)])
 print("life by (wg_id // 8) % 32 (CU within XCD?):", [round(float(np.median(life[ok & ((ids // 8) % 32 == k)])), 1) for k in range(32)])

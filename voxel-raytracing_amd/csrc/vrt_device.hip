@@ -1818,12 +1818,23 @@ __device__ __forceinline__ uchar4 denoise_pixel(const DenoiseParams& P, int px, 
 }
 
 // One TAP of a weighted pass with an integral tap offset R, the shader's own way: the tap's weight (cw * nw) * pw and its
-// colour texel (k_denoise_ver's redone pixels: sixteen lanes share a pixel, one tap each, so that a pixel costs one tap's
+// colour texel (k_denoise_ver's redone pixels: nine lanes share a pixel, one tap each, so that a pixel costs one tap's
 // chain of dependent instructions instead of nine; the sums are then taken by one lane in the shader's order).  The
 // arithmetic is denoise_pixel<false>'s, operation for operation.
+__device__ __forceinline__ float guides_tap_weight(float phi_color, float phi_normal, float phi_pos, float sw, const Guides& s, const Guides& o)
+{
+    const float sw2 = sw * sw;
+    float pw = edge_weight(dist2_4(s.p, o.p), phi_pos);
+    float cw = 1.0f, nw = 1.0f;
+    if (pw != 0.0f) {
+        cw = edge_weight(dist2_4(s.c, o.c), phi_color);
+        float dn = dist2_4(s.n, o.n);
+        nw = dn == 0.0f ? 1.0f : edge_weight(fmaxf(dn / sw2, 0.0f), phi_normal);
+    }
+    return (cw * nw) * pw;
+}
 __device__ __forceinline__ float denoise_tap_weight(const DenoiseParams& P, int px, int py, int tx, int ty, int R, uint32_t& color)
 {
-    const float sw = P.step_width, sw2 = sw * sw;
     Guides s, o;
     texel_guides(P, px + tx * R, py + ty * R, o);         // (both texels requested before either is used)
     texel_guides(P, px, py, s);
@@ -1833,14 +1844,7 @@ __device__ __forceinline__ float denoise_tap_weight(const DenoiseParams& P, int 
         y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
         color = reinterpret_cast<const uint32_t*>(P.color_in)[(size_t)y * (size_t)P.W + (size_t)x];
     }
-    float pw = edge_weight(dist2_4(s.p, o.p), P.phi_pos);
-    float cw = 1.0f, nw = 1.0f;
-    if (pw != 0.0f) {
-        cw = edge_weight(dist2_4(s.c, o.c), P.phi_color);
-        float dn = dist2_4(s.n, o.n);
-        nw = dn == 0.0f ? 1.0f : edge_weight(fmaxf(dn / sw2, 0.0f), P.phi_normal);
-    }
-    return (cw * nw) * pw;
+    return guides_tap_weight(P.phi_color, P.phi_normal, P.phi_pos, P.step_width, s, o);
 }
 
 template <bool PHI_INF>
@@ -2182,6 +2186,64 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
     }
 }
 
+#define VRT_DEN_FIXCAP 1024
+// The listed pixels of a workgroup, the shader's own way (k_denoise_ver, k_denoise_pair): nine lanes per listed pixel, a tap
+// each (denoise_tap_weight); then four of them a channel each, the sums in the shader's order.  More flagged than the list holds -- hostile
+// input -- or `all`: every pixel of the segment instead (columns xo .. xo + ow - 1, rows ys .. ye - 1; pixels that were sure get
+// the value they already have).  Called by every thread of the workgroup, behind the barrier that made n and the list final.
+template <bool SHIPPED, bool PASS0>
+__device__ __forceinline__ void denoise_redo(const DenoiseParams& P, int R, uint32_t n, bool all, int xo, int ow, int ys, int ye,
+                                             const uint32_t* fl_px, float (*fx_w)[9], uint32_t (*fx_c)[9], uint32_t first = 0u)
+{
+    constexpr int ntaps = SHIPPED ? 3 : 9;
+    const bool overflow = all || n > VRT_DEN_FIXCAP;
+    const uint32_t entries = overflow ? 64u * (uint32_t)(ye - ys) : n;
+    const bool shipped = SHIPPED;
+    // nine lanes per listed pixel: a tap each (denoise_tap_weight), then four of them a channel each -- the sums in the shader's order
+    const uint32_t per = blockDim.x / 9u, grp = threadIdx.x / 9u;          // pixels per round (fx_w, fx_c hold that many)
+    const int tap = (int)(threadIdx.x - grp * 9u);
+    int tx, ty;
+    if (shipped) { tx = tap == 0 ? -1 : (tap == 1 ? 1 : 0); ty = tap == 2 ? 0 : -1; }
+    else { tx = tap % 3 - 1; ty = tap / 3 - 1; }
+    for (uint32_t base = overflow ? 0u : first; base < entries; base += per) {        // (`first`: entries below it have been done)
+        const uint32_t e = base + grp;
+        bool live = grp < per && e < entries;
+        uint32_t idx = 0u;
+        if (live) {
+            if (overflow) { const uint32_t qx = (uint32_t)xo + (e & 63u); live = (int)(e & 63u) < ow && qx < (uint32_t)P.W; idx = (uint32_t)(ys + (int)(e >> 6)) * (uint32_t)P.W + qx; }
+            else idx = fl_px[e];
+        }
+        const int py = (int)(idx / (uint32_t)P.W), qx = (int)(idx - (uint32_t)py * (uint32_t)P.W);
+        if (live && tap < ntaps) {
+            uint32_t col;
+            float w = 1.0f;
+            if (PASS0) {
+                int x = qx + tx * R, y = py + ty * R;
+                x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+                y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+                col = reinterpret_cast<const uint32_t*>(P.color_in)[(size_t)y * (size_t)P.W + (size_t)x];
+            } else w = denoise_tap_weight(P, qx, py, tx, ty, R, col);
+            fx_w[grp][tap] = w; fx_c[grp][tap] = col;
+        }
+        __syncthreads();
+        if (live && tap < 4) {                                   // channel `tap` of the pixel
+            float sum = 0.0f, total = 0.0f;
+#pragma unroll
+            for (int i = 0; i < ntaps; i++) {
+                float kern;
+                if (shipped) kern = i == 1 ? kGauss0 : kGauss2;
+                else { const int ux = i % 3 - 1, uy = i / 3 - 1, r2 = ux * ux + uy * uy; kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2); }
+                const float w = fx_w[grp][i];
+                const float oc = decode_unorm8((fx_c[grp][i] >> (8 * tap)) & 0xFFu);
+                sum += (oc * w) * kern;
+                total += w * kern;
+            }
+            P.color_out[(size_t)idx * 4u + (size_t)tap] = unorm8(sum / total);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- the verified pass -----------------------------------------------------------------------------------------------------
 // vrt_denoise_bound.h: of a weighted pass only floor(mean * 255 + 0.5) is ever seen.  This kernel computes the mean cheaply --
 // code distances as exact integers (three v_dot4_u32_u8: |a - b|^2 = a.a + b.b - 2 a.b over the four bytes of a texel; normals
@@ -2197,7 +2259,6 @@ __global__ __launch_bounds__(256) void k_denoise_fast(const DenoiseParams P, int
 // into the ring slots of the four rows the group no longer needs.  A texel is fetched once per strip and segment (1.1 - 1.3x
 // the planes, against 1.9x for 64 x 8 tiles with their halo), the fetch latency hides under the arithmetic, and the launch is
 // ONE round of workgroups that all end together.  RT: the tap offset at compile time (LDS offsets become immediates), 0: any.
-#define VRT_DEN_FIXCAP 1024
 // u - 2 v (a shift and a subtraction).  Not as v_mad_i32_i24 through inline assembly: the result of a v_dot4 may not be read by
 // another vector instruction for three wait states on gfx950, and only instructions the compiler knows get their s_nops -- an
 // asm block here read stale registers; the compiler's own 24-bit multiply-add sign-extends first and is three instructions.
@@ -2208,8 +2269,8 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
     __shared__ uint32_t fl_n, fl_w4;
     __shared__ uint32_t fl_px[FLAG ? VRT_DEN_FIXCAP : 1];
-    __shared__ float fx_w[FLAG ? 16 : 1][9];
-    __shared__ uint32_t fx_c[FLAG ? 16 : 1][9];
+    __shared__ float fx_w[FLAG ? 28 : 1][9];
+    __shared__ uint32_t fx_c[FLAG ? 28 : 1][9];
 #ifdef VRT_K3_STAMPS
     // (development build, tools/exp_k3_timeline.py: a workgroup's start / ring filled / rows done / end on the 100 MHz clock, written
     // over the first words of color_out when it ends -- the image is garbage)
@@ -2393,59 +2454,269 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
 #endif
         if (n == 0u) return;                                     // uniform per workgroup
         if (P.fix_counts && threadIdx.x == 0) atomicAdd(&P.fix_counts[(blockIdx.y * gridDim.x + blockIdx.x) & (VRT_DENOISE_SEGS - 1u)], n);
-        {
-            // sixteen lanes per listed pixel, a tap each (denoise_tap_weight); lane 0 of the sixteen sums in the shader's order.
-            // (More flagged than the list holds -- hostile input --: every pixel of the segment instead; pixels that were sure
-            // get the value they already have.)
-            const bool overflow = n > VRT_DEN_FIXCAP;
-            const uint32_t entries = overflow ? 64u * (uint32_t)(ye - ys) : n;
-            const bool shipped = SHIPPED;
-            const int tap = (int)(threadIdx.x & 15u);
-            int tx, ty;
-            if (shipped) { tx = tap == 0 ? -1 : (tap == 1 ? 1 : 0); ty = tap == 2 ? 0 : -1; }
-            else { tx = tap % 3 - 1; ty = tap / 3 - 1; }
-            for (uint32_t base = 0; base < entries; base += 16u) {
-                const uint32_t e = base + (threadIdx.x >> 4);
-                bool live = e < entries;
-                uint32_t idx = 0u;
-                if (live) {
-                    if (overflow) { const uint32_t qx = (uint32_t)x0 + (e & 63u); live = qx < (uint32_t)P.W; idx = (uint32_t)(ys + (int)(e >> 6)) * (uint32_t)P.W + qx; }
-                    else idx = fl_px[e];
-                }
-                const int py = (int)(idx / (uint32_t)P.W), qx = (int)(idx - (uint32_t)py * (uint32_t)P.W);
-                if (live && tap < ntaps) {
-                    uint32_t col;
-                    float w = 1.0f;
-                    if (PASS0) {
-                        int x = qx + tx * R, y = py + ty * R;
-                        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
-                        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-                        col = reinterpret_cast<const uint32_t*>(P.color_in)[(size_t)y * (size_t)P.W + (size_t)x];
-                    } else w = denoise_tap_weight(P, qx, py, tx, ty, R, col);
-                    fx_w[threadIdx.x >> 4][tap] = w; fx_c[threadIdx.x >> 4][tap] = col;
-                }
-                __syncthreads();
-                if (live && tap == 0) {
-                    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, total = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < ntaps; i++) {
-                        float kern;
-                        if (shipped) kern = i == 1 ? kGauss0 : kGauss2;
-                        else { const int ux = i % 3 - 1, uy = i / 3 - 1, r2 = ux * ux + uy * uy; kern = r2 == 0 ? kGauss0 : (r2 == 1 ? kGauss1 : kGauss2); }
-                        const float w = fx_w[threadIdx.x >> 4][i];
-                        const uint32_t cc = fx_c[threadIdx.x >> 4][i];
-                        const float oc[4] = {decode_unorm8(cc & 0xFFu), decode_unorm8((cc >> 8) & 0xFFu), decode_unorm8((cc >> 16) & 0xFFu), decode_unorm8(cc >> 24)};
-                        for (int k = 0; k < 4; k++) sum[k] += (oc[k] * w) * kern;
-                        total += w * kern;
-                    }
-                    uchar4 out;
-                    out.x = unorm8(sum[0] / total); out.y = unorm8(sum[1] / total);
-                    out.z = unorm8(sum[2] / total); out.w = unorm8(sum[3] / total);
-                    reinterpret_cast<uchar4*>(P.color_out)[idx] = out;
-                }
-                __syncthreads();
-            }
+        denoise_redo<SHIPPED, PASS0>(P, R, n, false, x0, 64, ys, ye, fl_px, fx_w, fx_c);
+    }
+#ifdef VRT_K3_STAMPS
+    __syncthreads(); k3_stamp();
+#endif
+}
+
+// ---- the verified pass, every weight computed once (round 4) ---------------------------------------------------------------
+// The weight of a tap is symmetric: w(p, q) = w(q, p) -- integer code distances, squares of differences, the same kernel weight
+// for d and -d -- bit for bit in the arithmetic above.  Of the eight taps of a pixel p the four "forward" ones (1, 0), (-1, 1),
+// (0, 1), (1, 1) are computed by p's lane; the four "backward" ones are forward weights of the pixels R to the left / R rows
+// above.  A workgroup is R waves and a group of rows is R rows, one per wave, so that the row R above a wave's row is the row
+// the SAME wave did one group earlier: its three downward weights are still in registers (the one straight above stays in its
+// lane, the diagonal ones come through the crossbar, ds_bpermute), and the weight of the tap to the left is this row's own
+// (1, 0) of the lane R to the left.  Four exponentials per pixel instead of eight, no weight ever in memory; in exchange R rows
+// above every segment only compute downward weights and a wave's 64 lanes are 64 columns of which the inner 64 - 2 R produce
+// output.  The ring holds a texel as position x, y, z + the biased normal codes (16 B) and the four colour codes as halves
+// (8 B): exact in fp16, so the colour distance is four v_dot2_f32_f16 (integers below 2^24: exact in fp32 in any order) and a
+// tap's colour goes into the sums by v_fma_mix_f32 without a conversion.  The sums are taken in the order of k_denoise_ver
+// (centre, then taps 0 .. 8): the output is that kernel's bit for bit, redone pixels and all.  The position's w has a plane of its
+// own in the ring, read only once a texel with a w other than +-0 or a colour alpha has been met (K1 writes neither).
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+#ifndef VRT_PAIR_FIXCAP
+#define VRT_PAIR_FIXCAP 256     // listed pixels of a workgroup (of <= 58 x ~30): a few are listed, 2 % of a hostile frame; more: all of them redone
+#endif
+template <bool FLAG, int R>
+__global__ __launch_bounds__(64 * R) void k_denoise_pair(const DenoiseParams P, int seg_rows, int segs_per_strip)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_g[];
+    __shared__ uint32_t fl_n, fl_w4;
+    __shared__ uint32_t fl_px[VRT_PAIR_FIXCAP];
+    __shared__ float fx_w[(64 * R) / 9][9];
+    __shared__ uint32_t fx_c[(64 * R) / 9][9];
+#ifdef VRT_K3_STAMPS
+    uint32_t k3_t[4] = {(uint32_t)wall_clock64(), 0u, 0u, 0u};
+    uint32_t k3_redo = 0u;                                // (time inside the in-loop redo rounds; the stamp "ring filled" is moved back by it)
+    auto k3_stamp = [&]() {
+        if (threadIdx.x == 0) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(P.color_out) + 4u * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = k3_t[0]; o[1] = k3_t[1] + k3_redo; o[2] = k3_t[2]; o[3] = (uint32_t)wall_clock64();
         }
+    };
+#endif
+    constexpr int OW = 64 - 2 * R;                        // output columns of a strip
+    constexpr int UT = R * 64;                            // texels of a unit of R rows
+    constexpr int NT = 4 * UT;                            // ring: four units (three that a group reads + the one on its way in)
+    float4* lp = lds_g;                                   // x, y, z, biased normal codes
+    uint2* lh = reinterpret_cast<uint2*>(lds_g + NT);     // colour codes as four halves
+    float* lw = reinterpret_cast<float*>(lh + NT);        // position w (read by the general form of a row only)
+    const int x0 = blockIdx.x * OW;                       // first output column; lane l is column x0 - R + l
+    int ys, ye;
+    {
+        const int k = (int)blockIdx.y / segs_per_strip, j = (int)blockIdx.y - k * segs_per_strip;
+        const int g = k * P.sh.nranks + P.sh.rank;
+        int r0 = g * P.sh.strip_rows - P.extend, r1 = (g + 1) * P.sh.strip_rows;
+        r1 = (r1 < P.H ? r1 : P.H) + P.extend;
+        r0 = r0 < 0 ? 0 : r0; r1 = r1 < P.H ? r1 : P.H;
+        ys = r0 + j * seg_rows;
+        ye = ys + seg_rows < r1 ? ys + seg_rows : r1;
+    }
+    if (ys >= ye) return;                                 // uniform per workgroup
+    const int nrows = ye - ys;
+    const int groups = (nrows + 2 * R - 1) / R;           // centre rows f = 0 .. nrows + R - 1 in ring terms (ring row 0 = frame row ys - R)
+    if (threadIdx.x == 0) { fl_n = 0u; fl_w4 = 0u; }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l = threadIdx.x & 63, px = x0 - R + l;
+    // a lane's texel, the texel R to its left, the texel R to its right within this wave's row of a unit (the ends are never used)
+    const int tl = wave * 64 + l, tL = wave * 64 + (l - R < 0 ? 0 : l - R), tR = wave * 64 + (l + R > 63 ? 63 : l + R);
+    const int bL = (l - R < 0 ? 0 : l - R) << 2, bR = (l + R > 63 ? 63 : l + R) << 2;      // the same lanes for ds_bpermute
+    // a thread's texel of a unit: row `wave` of the unit, its own column (clamped to the frame: the ring holds copies of the border)
+    const uint32_t xA = (uint32_t)(px < 0 ? 0 : (px > P.W - 1 ? P.W - 1 : px));
+    const uint32_t* const gc = reinterpret_cast<const uint32_t*>(P.color_in);
+    const uint32_t* const gn = reinterpret_cast<const uint32_t*>(P.normal);
+    const float4* const gp = reinterpret_cast<const float4*>(P.position);
+    float4 pA = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t colA = 0u, nrmA = 0u;
+    auto fetch = [&](int unit) {                           // (the row is the wave's: a scalar base and the lane's column)
+        int yA = ys - R + R * unit + wave;
+        yA = yA < 0 ? 0 : (yA > P.H - 1 ? P.H - 1 : yA);
+        const size_t ro = (size_t)yA * (size_t)P.W;
+        pA = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gp + ro) + xA * 16u);
+        colA = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(gc + ro) + xA * 4u);
+        nrmA = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(gn + ro) + xA * 4u);
+    };
+    auto bias = [](uint32_t n) {                          // (k_denoise_ver's: SNORM -128 reads as -127, then every byte + 128)
+        uint32_t z = n ^ 0x80808080u;
+        z = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);
+        return (n | (z >> 7)) ^ 0x80808080u;
+    };
+    auto stash = [&](int slot) {
+        const int i = slot * UT + tl;
+        // (a colour alpha or a position w other than +-0: the rows take their general form from the next barrier on)
+        if ((colA >> 24) != 0u || (__float_as_uint(pA.w) << 1) != 0u) fl_w4 = 1u;
+        // codes as halves: 1024 + c is 0x6400 | c in fp16, exactly; minus 1024
+        const v2h k1024 = {(_Float16)1024.0f, (_Float16)1024.0f};
+        const v2h c01 = __builtin_bit_cast(v2h, __builtin_amdgcn_perm(colA, 0x64646464u, 0x00050004u)) - k1024;
+        const v2h c23 = __builtin_bit_cast(v2h, __builtin_amdgcn_perm(colA, 0x64646464u, 0x00070006u)) - k1024;
+        lp[i] = make_float4(pA.x, pA.y, pA.z, __uint_as_float(bias(nrmA)));
+        lh[i] = make_uint2(__builtin_bit_cast(uint32_t, c01), __builtin_bit_cast(uint32_t, c23));
+#ifndef VRT_PAIR_NOLW
+        lw[i] = pA.w;
+#endif
+    };
+    {
+        fetch(0);                                          // (both requested before the first is stored: one round trip)
+        const float4 qp = pA; const uint32_t qc = colA, qn = nrmA;
+        fetch(1);
+        const float4 rp = pA; const uint32_t rcol = colA, rn = nrmA;
+        pA = qp; colA = qc; nrmA = qn; stash(0);
+        pA = rp; colA = rcol; nrmA = rn; stash(1);
+    }
+    __syncthreads();
+#ifdef VRT_K3_STAMPS
+    k3_t[1] = (uint32_t)wall_clock64();
+#endif
+    const float kc = P.vkc, kn = P.vkn, kp = P.vkp;
+    const float half_guard = 0.5f - P.guard;
+    float pf1 = 0.0f, pf2 = 0.0f, pf3 = 0.0f;             // the downward weights (-1, 1), (0, 1), (1, 1) of this wave's row of the group before
+    // One centre row of a wave -- in ring slot S, the row below it in slot S + 1, the row above in slot S - 1 --: the forward
+    // weights of its 64 texels, and (`outrow`: it is a row of the segment) the pixel.
+    auto row = [&](auto w4_tag, auto s_tag, bool outrow, int py, uint32_t& out_codes, uint32_t& out_idx, bool& out_sure) {
+        constexpr bool W4 = decltype(w4_tag)::value;
+        constexpr int rc = decltype(s_tag)::value * UT, rf = ((decltype(s_tag)::value + 1) & 3) * UT, rb = ((decltype(s_tag)::value + 3) & 3) * UT;
+        const float4 s4 = lp[rc + tl];
+        const uint2 sh = lh[rc + tl];
+        const v2h s01 = __builtin_bit_cast(v2h, sh.x), s23 = __builtin_bit_cast(v2h, sh.y);
+        const v2h m01 = s01 * (_Float16)(-2.0f), m23 = s23 * (_Float16)(-2.0f);            // -2 s: |s - o|^2 = |s|^2 + |o|^2 + (-2 s) . o
+        const uint32_t sn = __float_as_uint(s4.w);
+        const float sw = W4 ? lw[rc + tl] : 0.0f;
+        const float scc = __builtin_amdgcn_fdot2(s01, s01, __builtin_amdgcn_fdot2(s23, s23, 0.0f, false), false);
+        const uint32_t snn = __builtin_amdgcn_udot4(sn, sn, 0u, false);
+        float wf[4]; uint2 hf[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ci = k == 0 ? rc + tR : (k == 1 ? rf + tL : (k == 2 ? rf + tl : rf + tR));
+            const float4 o4 = lp[ci];
+            const uint2 oh = lh[ci];
+            hf[k] = oh;
+            const v2h o01 = __builtin_bit_cast(v2h, oh.x), o23 = __builtin_bit_cast(v2h, oh.y);
+            const uint32_t on = __float_as_uint(o4.w);
+            // integers below 2^24 at every step: exact
+            const float dc = __builtin_amdgcn_fdot2(m23, o23, __builtin_amdgcn_fdot2(m01, o01, __builtin_amdgcn_fdot2(o23, o23, __builtin_amdgcn_fdot2(o01, o01, scc, false), false), false), false);
+            const int dn = mad24_minus2(__builtin_amdgcn_udot4(sn, on, 0u, false), __builtin_amdgcn_udot4(on, on, snn, false));
+            const float dx = s4.x - o4.x, dy = s4.y - o4.y, dz = s4.z - o4.z;
+            float dp = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (W4) { const float dw = sw - lw[ci]; dp = __builtin_fmaf(dw, dw, dp); }
+            const float lk = (k == 0 || k == 2) ? 0.18033688011112042f : 0.36067376022224085f;      // -log2(G1), -log2(G2)
+            const float e = __builtin_fmaf(dp, kp, __builtin_fmaf(dc, kc, __builtin_fmaf((float)dn, kn, lk)));
+            wf[k] = __builtin_amdgcn_exp2f(-e);
+        }
+        // the backward taps: (-1, -1) is the (1, 1) of the texel R left and R up, (0, -1) the (0, 1) of the texel R up, (1, -1) the
+        // (-1, 1) of the texel R right and R up, (-1, 0) the (1, 0) of the texel R to the left
+        const float w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bL, __float_as_int(pf3)));
+        const float w1 = pf2;
+        const float w2 = __int_as_float(__builtin_amdgcn_ds_bpermute(bR, __float_as_int(pf1)));
+        const float w3 = __int_as_float(__builtin_amdgcn_ds_bpermute(bL, __float_as_int(wf[0])));
+        pf1 = wf[1]; pf2 = wf[2]; pf3 = wf[3];
+        if (!outrow) return;
+        const uint2 h0 = lh[rb + tL], h1 = lh[rb + tl], h2 = lh[rb + tR], h3 = lh[rc + tL];
+        constexpr float kcen = kGauss0;
+        float a0 = (float)s01.x * kcen, a1 = (float)s01.y * kcen, a2 = (float)s23.x * kcen, a3 = W4 ? (float)s23.y * kcen : 0.0f;
+        float total = kcen;
+        auto acc = [&](const uint2& h, float wk) {
+            const v2h c01 = __builtin_bit_cast(v2h, h.x), c23 = __builtin_bit_cast(v2h, h.y);
+            a0 = __builtin_fmaf((float)c01.x, wk, a0);
+            a1 = __builtin_fmaf((float)c01.y, wk, a1);
+            a2 = __builtin_fmaf((float)c23.x, wk, a2);
+            if (W4) a3 = __builtin_fmaf((float)c23.y, wk, a3);
+            total += wk;
+        };
+        acc(h0, w0); acc(h1, w1); acc(h2, w2); acc(h3, w3);              // taps 0 .. 3
+        acc(hf[0], wf[0]); acc(hf[1], wf[1]); acc(hf[2], wf[2]); acc(hf[3], wf[3]);   // taps 5 .. 8
+        const float r = __builtin_amdgcn_rcpf(total);
+        const float y0f = __builtin_fmaf(a0, r, 0.5f), y1f = __builtin_fmaf(a1, r, 0.5f), y2f = __builtin_fmaf(a2, r, 0.5f);
+        const float f0 = __builtin_amdgcn_fractf(y0f), f1 = __builtin_amdgcn_fractf(y1f), f2 = __builtin_amdgcn_fractf(y2f);
+        const uint32_t o0 = (uint32_t)y0f, o1 = (uint32_t)y1f, o2 = (uint32_t)y2f;
+        bool sure = !FLAG || (__builtin_fabsf(f0 - 0.5f) < half_guard && __builtin_fabsf(f1 - 0.5f) < half_guard && __builtin_fabsf(f2 - 0.5f) < half_guard);
+        uint32_t o3 = 0u;
+        if (W4) {
+            const float y3f = __builtin_fmaf(a3, r, 0.5f), f3 = __builtin_amdgcn_fractf(y3f);
+            o3 = (uint32_t)y3f;
+            if (FLAG) sure = sure && __builtin_fabsf(f3 - 0.5f) < half_guard;
+        }
+        out_codes = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24); out_idx = (uint32_t)py * (uint32_t)P.W + (uint32_t)px; out_sure = sure;
+    };
+    // Group g: the centre rows R g .. R g + R - 1, one per wave, in ring slot g & 3.  They read units g - 1, g, g + 1; unit g + 2
+    // arrives meanwhile and goes into the slot of unit g - 2.  (Four groups per turn of the loop: the slots are constants and every
+    // LDS address is a lane's base + an immediate.)
+    auto step = [&](auto s_tag, int g) {
+        constexpr int S = decltype(s_tag)::value;
+        const bool more = g + 1 < groups;
+#ifndef VRT_PAIR_NOPRIO
+        // The scheduler serves the oldest wave first: of the workgroups of a compute unit the youngest would be left to finish alone,
+        // one wave per SIMD.  A wave's priority falls as it gets on, so that whoever is behind goes first and all end together.
+        {
+#ifndef VRT_PAIR_STAGGER
+#define VRT_PAIR_STAGGER 0
+#endif
+            const int q = VRT_PAIR_STAGGER ? (4 * (g + (int)(blockIdx.y & 3u) * groups / VRT_PAIR_STAGGER)) / (groups + 3 * groups / VRT_PAIR_STAGGER + 1) : (4 * g) / groups;
+            if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
+        if (more) fetch(g + 2);
+        const int f = R * g + wave, py = ys + f - R;
+        const bool outrow = g >= 1 && py < ye;
+        const bool have = outrow && l >= R && l < 64 - R && px < P.W;
+        uint32_t out_codes = 0u, out_idx = 0u;
+        bool out_sure = true;
+        const bool w4 = fl_w4 != 0u;
+        if (f < nrows + R) {                                         // (uniform per wave; every lane computes its texel's weights)
+            if (w4) row(std::true_type{}, s_tag, outrow, py, out_codes, out_idx, out_sure);
+            else    row(std::false_type{}, s_tag, outrow, py, out_codes, out_idx, out_sure);
+        }
+        if (more) stash((S + 2) & 3);
+        if (have) {
+            if (out_sure) reinterpret_cast<uint32_t*>(P.color_out)[out_idx] = out_codes;
+            else if (FLAG) { const uint32_t slot = atomicAdd(&fl_n, 1u); if (slot < VRT_PAIR_FIXCAP) fl_px[slot] = out_idx; }
+        }
+        __syncthreads();
+    };
+    uint32_t done = 0u;                                               // listed pixels already evaluated the shader's own way
+    for (int g = 0; g < groups; g += 4) {
+        if (FLAG && g > 0) {
+            // The pixels listed so far, now -- under the other workgroups' rows -- rather than all at the end of the launch, where every
+            // workgroup would stand in this chain of dependent instructions at once with nothing to hide it.  (The barrier: nobody
+            // lists a pixel of the next group before everybody has read the count.)
+            const uint32_t n = fl_n < VRT_PAIR_FIXCAP ? fl_n : VRT_PAIR_FIXCAP;
+            __syncthreads();
+#ifdef VRT_K3_STAMPS
+            const uint32_t k3_r0 = (uint32_t)wall_clock64();
+#endif
+#ifndef VRT_PAIR_EXP_NOREDO
+            if (n > done) { denoise_redo<false, false>(P, R, n, false, x0, OW, ys, ye, fl_px, fx_w, fx_c, done); done = n; }
+#endif
+#ifdef VRT_K3_STAMPS
+            k3_redo += (uint32_t)wall_clock64() - k3_r0;
+#endif
+        }
+        step(std::integral_constant<int, 0>{}, g);
+        if (g + 1 >= groups) break;
+        step(std::integral_constant<int, 1>{}, g + 1);
+        if (g + 2 >= groups) break;
+        step(std::integral_constant<int, 2>{}, g + 2);
+        if (g + 3 >= groups) break;
+        step(std::integral_constant<int, 3>{}, g + 3);
+    }
+#ifdef VRT_K3_STAMPS
+    k3_t[2] = (uint32_t)wall_clock64();
+#endif
+    if (FLAG) {
+        // (the loop's last barrier is behind us: fl_n and fl_px are final)
+        const uint32_t n = fl_n;
+        if (n > done) {                                              // uniform per workgroup
+#ifndef VRT_PAIR_NOPRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+#ifndef VRT_PAIR_EXP_NOREDO
+            denoise_redo<false, false>(P, R, n, n > VRT_PAIR_FIXCAP, x0, OW, ys, ye, fl_px, fx_w, fx_c, done);
+#endif
+        }
+        if (n != 0u && P.fix_counts && threadIdx.x == 0) atomicAdd(&P.fix_counts[(blockIdx.y * gridDim.x + blockIdx.x) & (VRT_DENOISE_SEGS - 1u)], n);
     }
 #ifdef VRT_K3_STAMPS
     __syncthreads(); k3_stamp();
@@ -2465,7 +2736,35 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     int R = (int)sw;
     bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
     const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
-    if ((float)R == sw && R >= 1 && R <= 5 && p.verified && !(inf && (p.mode & VRT_DENOISE_FAST))) {
+    if ((float)R == sw && R >= 2 && R <= 5 && p.verified && !inf && !shipped && !p.no_pair) {
+        // the verified pass with every weight computed once (k_denoise_pair): strips of 64 - 2 R output columns x seg_rows rows, R waves
+        // per workgroup, as many waves in the launch as k_denoise_ver's (p.pair_wgs > 0: that many workgroups instead)
+        const int ow = 64 - 2 * R;
+        const int strips = (p.W + ow - 1) / ow;
+        const int strip_ext = p.sh.nranks == 1 ? p.H : per;
+        const int total = p.sh.nranks == 1 ? p.H : rows;
+        int wgs = (p.pair_wgs > 0 ? p.pair_wgs : 4096 / R) / strips; if (wgs < 1) wgs = 1;
+        int seg_rows = ((total + wgs - 1) / wgs + R - 1) / R * R; if (seg_rows < 2 * R) seg_rows = 2 * R;
+        const int segs = (strip_ext + seg_rows - 1) / seg_rows;
+        dim3 g2((unsigned)strips, (unsigned)(segs * p.sh.n_local_strips));
+#ifdef VRT_PAIR_NOLW
+        const size_t l2 = (size_t)(4 * R) * 64 * 24;
+#else
+        const size_t l2 = (size_t)(4 * R) * 64 * 28;
+#endif
+        const bool flag = !(p.mode & VRT_DENOISE_FAST);
+#define VRT_LAUNCH_PAIR(R_)                                                                                                       \
+        if (flag) hipLaunchKernelGGL((k_denoise_pair<true, R_>), g2, dim3(64 * R_), l2, s, p, seg_rows, segs);                     \
+        else      hipLaunchKernelGGL((k_denoise_pair<false, R_>), g2, dim3(64 * R_), l2, s, p, seg_rows, segs);
+        switch (R) {
+        case 2:  VRT_LAUNCH_PAIR(2) break;
+        case 3:  VRT_LAUNCH_PAIR(3) break;
+        case 4:  VRT_LAUNCH_PAIR(4) break;
+        default: VRT_LAUNCH_PAIR(5) break;
+        }
+#undef VRT_LAUNCH_PAIR
+    }
+    else if ((float)R == sw && R >= 1 && R <= 5 && p.verified && !(inf && (p.mode & VRT_DENOISE_FAST))) {
         // the verified pass (exact output) or, with VRT_DENOISE_FAST, its cheap half alone: 64-pixel column strips x seg_rows rows of
         // the rank's strips (with the rows either side this pass must also produce), about four workgroups per compute unit
         // (768 ... 2048 measured the same); pass 0: the ring holds the colour plane only -- 34 VGPRs, 9 KB of LDS: eight
