@@ -255,3 +255,32 @@ def test_verified_pass_when_every_pixel_is_redone(vrt, oracle, engine):
             engine.set_option("denoise_count", 0)
         exp = oracle.denoise(color, nrm, pos, iterations=3, mode=mode)
         assert (got == exp).all(), int((got != exp).sum())
+
+
+@pytest.mark.parametrize("size", [(200, 120), (333, 61), (59, 9), (1, 1), (117, 400)])
+def test_pair_kernel_is_the_ver_kernel(vrt, oracle, engine, size):
+    """Round 4: k_denoise_pair (every weight computed once, R waves per workgroup, 64 - 2 R output columns per strip) against
+    k_denoise_ver (context option denoise_pair = 0) and the oracle, on hostile G-buffers: tap offsets 2 .. 5, the exact mode and
+    VRT_DENOISE_FAST (the same cheap arithmetic in both kernels: bit-identical there too), the same pixels evaluated twice."""
+    import torch
+    W, H = size
+    rng = np.random.default_rng(W * 77 + H)
+    color, nrm, pos = _hostile_gbuffer(rng, W, H)
+    dev = engine.torch_device
+    c, n, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (color, nrm, pos))
+    for iterations, step in ((2, 1.0), (3, 2.0), (2, 3.0), (2, 4.0), (3, 1.0)):              # weighted passes with offsets 2; 3, 5; 4; 5; 2, 3
+        for mode in (0, vrt.DENOISE_FAST):
+            st = vrt.VoxelRenderSettings(targetResolution=(W, H))
+            d = st.denoiserSettings
+            d.iterations, d.stepWidth, d.mode = iterations, step, mode
+            out, redone = {}, {}
+            for pair in (1, 0):
+                with engine.options(denoise_pair=pair, denoise_count=1):
+                    stage = vrt.DenoiserStage(engine, st)
+                    out[pair] = stage.record(c, n, p).cpu().numpy().copy()
+                    redone[pair] = [stage.redone(i) for i in range(iterations)]
+            assert (out[1] == out[0]).all(), (iterations, step, mode, int((out[1] != out[0]).sum()))
+            assert redone[1] == redone[0], (iterations, step, mode, redone)
+            if mode == 0:
+                exp = oracle.denoise(color, nrm, pos, iterations=iterations, step_width0=step, mode=0)
+                assert (out[1] == exp).all(), (iterations, step, int((out[1] != exp).sum()))

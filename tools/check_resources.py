@@ -35,6 +35,10 @@ BUDGET = {
     "k_denoise_verILb0ELb1ELi3ELb0EE": ("K3 verified weighted pass, tap offset 3 (the reference's pass 1)", 96, 96, 0),
     "k_denoise_verILb0ELb1ELi5ELb0EE": ("K3 verified weighted pass, tap offset 5 (the reference's pass 2)", 96, 96, 0),
     "k_denoise_verILb0ELb1ELi1ELb1EE": ("K3 verified pass 0", 64, 96, 0),
+    # (round 4, every weight computed once: R waves per workgroup, five to six workgroups per compute unit by LDS: 96 VGPRs leave five waves per SIMD)
+    "k_denoise_pairILb1ELi3EE": ("K3 verified weighted pass, every weight once, tap offset 3 (the reference's pass 1)", 96, 96, 0),
+    "k_denoise_pairILb1ELi5EE": ("K3 verified weighted pass, every weight once, tap offset 5 (the reference's pass 2)", 96, 96, 0),
+    "k_denoise_pairILb0ELi3EE": ("K3 VRT_DENOISE_FAST weighted pass, every weight once, tap offset 3", 96, 96, 0),
 }
 
 

@@ -2424,6 +2424,11 @@ __global__ __launch_bounds__(256) void k_denoise_ver(const DenoiseParams P, int 
     };
     for (int g = 0; g < groups; g++) {
         const bool more = g + 1 < groups;
+#ifdef VRT_VER_PRIO
+        // (a wave's priority falls as it gets on: see k_denoise_pair)
+        if (4 * g < groups) __builtin_amdgcn_s_setprio(3); else if (2 * g < groups) __builtin_amdgcn_s_setprio(2);
+        else if (4 * g < 3 * groups) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         if (more) fetch(g + U);                                  // the unit group g + 1 adds: in flight while group g is filtered
         const int yr = 4 * g + wave, py = ys + yr;               // relative row of the output; its taps' rows are yr, yr + R, yr + 2R in ring terms
         const bool have = py < ye && px < P.W;
@@ -2650,12 +2655,8 @@ __global__ __launch_bounds__(64 * R) void k_denoise_pair(const DenoiseParams P, 
         // The scheduler serves the oldest wave first: of the workgroups of a compute unit the youngest would be left to finish alone,
         // one wave per SIMD.  A wave's priority falls as it gets on, so that whoever is behind goes first and all end together.
         {
-#ifndef VRT_PAIR_STAGGER
-#define VRT_PAIR_STAGGER 0
-#endif
-            const int q = VRT_PAIR_STAGGER ? (4 * (g + (int)(blockIdx.y & 3u) * groups / VRT_PAIR_STAGGER)) / (groups + 3 * groups / VRT_PAIR_STAGGER + 1) : (4 * g) / groups;
-            if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2);
-            else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            if (4 * g < groups) __builtin_amdgcn_s_setprio(3); else if (2 * g < groups) __builtin_amdgcn_s_setprio(2);
+            else if (4 * g < 3 * groups) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
 #endif
         if (more) fetch(g + 2);
@@ -2743,7 +2744,9 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
         const int strips = (p.W + ow - 1) / ow;
         const int strip_ext = p.sh.nranks == 1 ? p.H : per;
         const int total = p.sh.nranks == 1 ? p.H : rows;
+        // (as many waves as k_denoise_ver's launch, and no segment much longer than 48 rows: 4K measured 105 against 109 us for two passes)
         int wgs = (p.pair_wgs > 0 ? p.pair_wgs : 4096 / R) / strips; if (wgs < 1) wgs = 1;
+        if (p.pair_wgs <= 0 && wgs < (total + 47) / 48) wgs = (total + 47) / 48;
         int seg_rows = ((total + wgs - 1) / wgs + R - 1) / R * R; if (seg_rows < 2 * R) seg_rows = 2 * R;
         const int segs = (strip_ext + seg_rows - 1) / seg_rows;
         dim3 g2((unsigned)strips, (unsigned)(segs * p.sh.n_local_strips));
