@@ -14,13 +14,16 @@ import voxel_raytracing_amd as vrt
 scenes, n = "tmb", 5
 eng = vrt.Engine(0)
 for a in sys.argv[1:]:
+    if "=" not in a: continue
     k, v = a.split("=")
     if k == "scenes": scenes = v
     elif k == "n": n = int(v)
+    elif k == "stats": pass
     else: eng.set_option(k, int(v))
 pal = vrt.synthetic.default_palette(metallic_ids=range(200, 256))
 sky, noise = vrt.synthetic.sky_gradient(512, 256), vrt.synthetic.blue_noise_standin(512)
-VARIANTS = (("primary", 0, False, 0), ("shadow", 0, True, 0), ("ao4", 4, False, 0), ("ao4+shadow", 4, True, 0), ("full", 4, True, None))
+VARIANTS = (("primary", 0, False, 0), ("shadow", 0, True, 0), ("ao4", 4, False, 0), ("ao4+shadow", 4, True, 0), ("full", 4, True, None),
+            ("bounces-only", 0, False, None))       # (the last: bounce rays without any AO / shadow ray -- what the chain's main rays cost)
 
 
 def run(tag, scene, res, dims, pos, max_steps, bounces, frame):
@@ -41,6 +44,20 @@ def run(tag, scene, res, dims, pos, max_steps, bounces, frame):
             t.append(eng.last_timings()["geometry_ms"])
         t = sorted(t[1:]) if n > 1 else t
         print(f"VARIANT {tag} {name} launches={n} geometry_us={t[len(t) // 2] * 1e3:.1f}", flush=True)
+        if name == "full" and "stats" in sys.argv[1:]:
+            # how the chain's rays sit in the waves: pixels whose primary hit reflects, per 8 x 8 tile (a wave of K1)
+            gb = vrt.GeometryBuffer(eng, res[0], res[1], ["rays_total", "hit_id"])
+            stc, fr = st.to_c(), gb.to_c()
+            import ctypes as C
+            vrt._capi.check(vrt.lib().vrt_render_geometry(eng.ctx, scene.handle, C.byref(push), C.byref(stc), C.byref(fr), None)); eng.synchronize()
+            g = gb.numpy()
+            hit = g["hit_id"] != 0
+            metal = g["hit_id"] >= 200
+            H8, W8 = res[1] // 8 * 8, res[0] // 8 * 8
+            tm = metal[:H8, :W8].reshape(H8 // 8, 8, W8 // 8, 8).sum((1, 3))
+            th = hit[:H8, :W8].reshape(H8 // 8, 8, W8 // 8, 8).sum((1, 3))
+            print(f"STATS {tag}: hit {hit.mean():.3f} of the pixels, reflecting {metal.mean():.3f}; waves with a hit {np.mean(th > 0):.3f}, with a reflecting hit {np.mean(tm > 0):.3f}, "
+                  f"reflecting lanes in those {tm[tm > 0].mean():.1f} of 64; rays per pixel {g['rays_total'].mean():.2f}", flush=True)
 
 
 if "t" in scenes:

@@ -150,6 +150,26 @@ for tag in ("config3", "defaults", "mandelbulb", "brick"):
 for name, row in st_cfg.items():
     if "k_denoise" in name or "k_primary" in name:
         lines.append(f"| configurations under rocprofv3 --kernel-trace: `{name[:60]}` | {us(row):.1f} us avg, {float(row['MinNs']) / 1e3:.1f} min, {row['Calls']} calls | profiles/r04_configs_kernel_stats.csv | same |")
+K3_BYTES = {"k_denoise": 28, "k_denoise_fast": 28, "k_denoise_literal": 28, "k_denoise_pass0": 8, "k_denoise_pass0_literal": 8}     # bytes per pixel and pass
+for nm, bpp in K3_BYTES.items():
+    f = f"profiles/r04_{nm}_pmc.json"
+    if not os.path.exists(f):
+        continue
+    j = json.load(open(f))
+    if j.get("csrc_sha16") != csrc_sha16():
+        continue
+    h, c = j.get("hbm_bytes_per_launch"), j["counters"]
+    alg = 1920 * 1080 * bpp
+    kn = (j.get("kernel") or "")[:48]
+    if h:
+        lines.append(f"| K3 `{kn}`: HBM bytes per pass (guide rule / raw fetch / written) against {alg / 1e6:.2f} MB by the accounting | {h['total_guide_rule'] / 1e6:.1f} / {h['total_raw_fetch'] / 1e6:.1f} / {h['write'] / 1e6:.1f} MB = "
+                     f"{h['total_guide_rule'] / alg:.2f}x / {h['total_raw_fetch'] / alg:.2f}x | {f} | hbm_bytes_per_launch |")
+    if "SQ_INSTS_VALU" in c:
+        v = c["SQ_INSTS_VALU"]["mean_per_launch"]
+        lines.append(f"| K3 `{kn}`: vector instructions per pass; issue time | {v / 1e6:.2f} M; {v * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e6:.1f} us | {f} | counters.SQ_INSTS_VALU |")
+for name, row in st_cfg.items():
+    if "k_denoise_pair<true, 3>" in name:
+        lines.append(f"| K3 weighted pass at 1080p, exact output: accounting bytes / kernel time / HBM peak | {1920 * 1080 * 28 / 1e6:.2f} MB / {us(row):.1f} us = {1920 * 1080 * 28 / (us(row) * 1e-6) / 8e12:.3f} of 8 TB/s | profiles/r04_configs_kernel_stats.csv | `{name[:50]}` |")
 for tag, (g, dn) in plain.items():
     if dn > 0:
         lines.append(f"| {tag}: two denoiser passes, library events, no profiler | {dn} us | profiles/r04_configs_plain.log | VARIANT {tag} denoise_us |")
