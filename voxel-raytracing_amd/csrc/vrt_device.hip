@@ -2737,7 +2737,9 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     int R = (int)sw;
     bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
     const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
-    if ((float)R == sw && R >= 2 && R <= 5 && p.verified && !inf && !shipped && !p.no_pair) {
+    // (a rank's 16-row strips are too short for it -- R rows above every segment only compute weights --: two passes over rank 0's strips of
+    // 2 / 4 / 8 ranks 29.8 / 18.5 / 14.2 us against k_denoise_ver's 27.0 / 19.5 / 13.9, tools/exp_r4_k3_shard.py; bands of 64 rows and more take it)
+    if ((float)R == sw && R >= 2 && R <= 5 && p.verified && !inf && !shipped && !p.no_pair && (p.sh.nranks == 1 || per >= 64)) {
         // the verified pass with every weight computed once (k_denoise_pair): strips of 64 - 2 R output columns x seg_rows rows, R waves
         // per workgroup, as many waves in the launch as k_denoise_ver's (p.pair_wgs > 0: that many workgroups instead)
         const int ow = 64 - 2 * R;
