@@ -284,3 +284,28 @@ def test_pair_kernel_is_the_ver_kernel(vrt, oracle, engine, size):
             if mode == 0:
                 exp = oracle.denoise(color, nrm, pos, iterations=iterations, step_width0=step, mode=0)
                 assert (out[1] == exp).all(), (iterations, step, int((out[1] != exp).sum()))
+
+
+@pytest.mark.parametrize("size", [(200, 120), (61, 333), (62, 8), (63, 9), (1, 1), (125, 7)])
+def test_pass0_kernel_is_the_ver_kernel(vrt, oracle, engine, size):
+    """Round 4: k_denoise_p0 (pass 0, a wave to itself: 62 output columns, neighbours through wave_shr / wave_shl, the kernel taken
+    separably) against k_denoise_ver<.., PASS0> (context option denoise_p0 = 0) and the oracle, hostile colours with and without
+    alpha; strips of exactly 62 and 63 columns."""
+    import torch
+    W, H = size
+    rng = np.random.default_rng(W * 131 + H)
+    color, nrm, pos = _hostile_gbuffer(rng, W, H)
+    dev = engine.torch_device
+    for alpha in (True, False):
+        if not alpha: color = color.copy(); color[..., 3] = 0
+        c, n, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (color, nrm, pos))
+        for iterations in (1, 2):
+            st = vrt.VoxelRenderSettings(targetResolution=(W, H))
+            st.denoiserSettings.iterations = iterations
+            out = {}
+            for p0 in (1, 0):
+                with engine.options(denoise_p0=p0):
+                    out[p0] = vrt.DenoiserStage(engine, st).record(c, n, p).cpu().numpy().copy()
+            exp = oracle.denoise(color, nrm, pos, iterations=iterations)
+            assert (out[1] == exp).all(), (alpha, iterations, int((out[1] != exp).sum()))
+            assert (out[0] == exp).all(), (alpha, iterations, int((out[0] != exp).sum()))

@@ -39,6 +39,7 @@ BUDGET = {
     "k_denoise_pairILb1ELi3EE": ("K3 verified weighted pass, every weight once, tap offset 3 (the reference's pass 1)", 96, 96, 0),
     "k_denoise_pairILb1ELi5EE": ("K3 verified weighted pass, every weight once, tap offset 5 (the reference's pass 2)", 96, 96, 0),
     "k_denoise_pairILb0ELi3EE": ("K3 VRT_DENOISE_FAST weighted pass, every weight once, tap offset 3", 96, 96, 0),
+    "k_denoise_p0ILb1EE": ("K3 verified pass 0, a wave to itself (no LDS ring, no barrier)", 64, 96, 0),
 }
 
 

@@ -59,6 +59,7 @@ struct DevOptions {
     int denoise_th16 = 0;      // the tolerance denoiser on 64 x 16 tiles
     int denoise_packed = 1;    // the exact weighted pass two taps at a time in packed fp32
     int denoise_pair = 1;      // verified passes of the canonical taps with an offset of 2 .. 5 through k_denoise_pair (every weight computed once)
+    int denoise_p0 = 1;        // verified pass 0 of the canonical taps through k_denoise_p0 (a wave to itself: no LDS, no barrier)
     int denoise_pair_wgs = 0;  // (experiments) workgroups of a k_denoise_pair launch; 0: as many waves as k_denoise_ver's 1024 workgroups
     int denoise_verified = 1;  // weighted passes through k_denoise_ver (vrt_denoise_bound.h); 0: the exact kernels compute every pixel
     int denoise_guard_div8 = 0;// (tests) an eighth of the guard: how much room the bound leaves
@@ -75,7 +76,7 @@ static const OptName kOptNames[] = {
     {"packed_bounces", "VRT_PACKED_BOUNCES", &DevOptions::packed_bounces}, {"ao_batch", "VRT_AO_BATCH", &DevOptions::ao_batch}, {"tags_async", "VRT_TAGS_ASYNC", &DevOptions::tags_async},
     {"hit_table", "VRT_HIT_TABLE", &DevOptions::hit_table},
     {"thresh_runs", "VRT_THRESH_RUNS", &DevOptions::thresh_runs}, {"denoise_th16", "VRT_DENOISE_TH", &DevOptions::denoise_th16}, {"denoise_packed", "VRT_DENOISE_PACKED", &DevOptions::denoise_packed},
-    {"denoise_pair", "VRT_DENOISE_PAIR", &DevOptions::denoise_pair}, {"denoise_pair_wgs", "VRT_DENOISE_PAIR_WGS", &DevOptions::denoise_pair_wgs},
+    {"denoise_pair", "VRT_DENOISE_PAIR", &DevOptions::denoise_pair}, {"denoise_p0", "VRT_DENOISE_P0", &DevOptions::denoise_p0}, {"denoise_pair_wgs", "VRT_DENOISE_PAIR_WGS", &DevOptions::denoise_pair_wgs},
     {"denoise_verified", "VRT_DENOISE_VERIFIED", &DevOptions::denoise_verified}, {"denoise_guard_div8", "VRT_DENOISE_GUARD_DIV8", &DevOptions::denoise_guard_div8},
     {"denoise_count", "VRT_DENOISE_COUNT", &DevOptions::denoise_count},
     {"open_cells", "VRT_OPEN_CELLS", &DevOptions::open_cells}, {"df_prefetch", "VRT_DF_PREFETCH", &DevOptions::df_prefetch},
@@ -1254,7 +1255,7 @@ int vrt_denoise(vrt_ctx* c, int32_t W, int32_t H, const vrt_denoiser_settings* d
     if (rc != VRT_OK) return rc;
     p.normal = normal8; p.position = position; p.W = W; p.H = H; p.mode = ds->mode;
     p.tile16 = c->opt.denoise_th16; p.no_packed = c->opt.denoise_packed ? 0 : 1;
-    p.no_pair = c->opt.denoise_pair ? 0 : 1; p.pair_wgs = c->opt.denoise_pair_wgs;
+    p.no_pair = c->opt.denoise_pair ? 0 : 1; p.no_p0 = c->opt.denoise_p0 ? 0 : 1; p.pair_wgs = c->opt.denoise_pair_wgs;
     uint8_t* targets[2] = {target0, target1};
     const uint8_t* last = color_in;
     // which passes take the verified form (an integral tap offset, a guard worth having)

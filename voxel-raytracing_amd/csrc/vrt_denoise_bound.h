@@ -78,6 +78,11 @@ inline double denoise_guard(double phi_color, double phi_normal, double phi_pos,
 // relative on a value <= 1, then 511 eps codes of the two final roundings.  The cheap form: nine fused accumulations of
 // code * kappa, the reciprocal of the weights' sum rounded once from double (the sum of the Gaussians themselves: within 2 eps
 // of the sum of the spec's fp32 constants), one fused multiply-add: 12.1 eps relative, 256 eps.
+// The separable cheap form (k_denoise_p0, round 4): h = fma(l, g, fma(r, g, c)) per row and fma(h_up, g, fma(h_down, g, h)) per pixel
+// with g the fp32 constant kappa_1.  Edge taps weigh exactly kappa_1; corner taps weigh kappa_1^2, within 3.01 eps (relative) of the
+// spec's kappa_2 (each constant is the Gaussian G1, G2 = G1^2 rounded once), and carry 4 kappa_2 / sum = 0.41 of the weight: 1.24 eps
+// on the mean.  Four fused roundings, each at most eps of the final sum (every term is non-negative): 4 eps.  The reciprocal and the
+// last multiply-add as above: 3.1 eps, 256 eps.  8.4 eps relative: inside the 12.1 the guard is made of.
 inline double denoise_guard_pass0()
 {
     return 1.01 * 255.0 * (19.2 + 12.1) * kDenEps + 767.0 * kDenEps;

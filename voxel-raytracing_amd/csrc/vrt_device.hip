@@ -2724,6 +2724,109 @@ __global__ __launch_bounds__(64 * R) void k_denoise_pair(const DenoiseParams P, 
 #endif
 }
 
+// ---- pass 0, a wave to itself (round 4) --------------------------------------------------------------------------------------
+// phi = +inf: every edge-stopping weight is exactly 1 and the pass is a 3 x 3 blur of the colour plane with the tap offset 1.  A
+// wave owns 62 output columns (its 64 lanes are the columns x0 - 1 .. x0 + 62) and SEG rows: it requests the SEG + 2 rows of its
+// column once, all before the first is used, and walks down them with the three rows it needs as floats in registers -- a lane's
+// left and right neighbours come through the data-parallel shifts (wave_shr / wave_shl), no LDS, no barrier, nothing shared with
+// another wave.  The kernel is separable -- (g, 1, g) x (g, 1, g) with g = G1 = exp(-1/8), G2 = G1^2 --, so a row's horizontal sums
+// fma(l, g, fma(r, g, c)) are taken once, when the row arrives, and an output row is fma(h_up, g, fma(h_down, g, h)): four fused
+// multiply-adds per channel instead of eight.  That is another cheap form than k_denoise_ver<.., PASS0>'s, under the same guard
+// (vrt_denoise_bound.h, denoise_guard_pass0, derives both); the pixels within the guard -- a dozen to a hundred per frame -- go
+// through denoise_redo at the end.
+#ifndef VRT_P0_SEG
+#define VRT_P0_SEG 8
+#endif
+template <bool FLAG>
+__global__ __launch_bounds__(64) void k_denoise_p0(const DenoiseParams P, int segs_per_strip)
+{
+    __shared__ uint32_t fl_px[64];
+    __shared__ float fx_w[7][9];
+    __shared__ uint32_t fx_c[7][9];
+    constexpr int OW = 62, SEG = VRT_P0_SEG;
+    const int x0 = blockIdx.x * OW;
+    int ys, ye;
+    {
+        const int k = (int)blockIdx.y / segs_per_strip, j = (int)blockIdx.y - k * segs_per_strip;
+        const int g = k * P.sh.nranks + P.sh.rank;
+        int r0 = g * P.sh.strip_rows - P.extend, r1 = (g + 1) * P.sh.strip_rows;
+        r1 = (r1 < P.H ? r1 : P.H) + P.extend;
+        r0 = r0 < 0 ? 0 : r0; r1 = r1 < P.H ? r1 : P.H;
+        ys = r0 + j * SEG;
+        ye = ys + SEG < r1 ? ys + SEG : r1;
+    }
+    if (ys >= ye) return;                                 // uniform
+    const int l = threadIdx.x, px = x0 - 1 + l;
+    const uint32_t xA = (uint32_t)(px < 0 ? 0 : (px > P.W - 1 ? P.W - 1 : px));
+    const uint32_t* const gc = reinterpret_cast<const uint32_t*>(P.color_in);
+    uint32_t code[SEG + 2];
+#pragma unroll
+    for (int q = 0; q < SEG + 2; q++) {                   // rows ys - 1 .. ys + SEG, clamped to the frame (rows beyond ye + 1 are never used)
+        int y = ys - 1 + q;
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+        code[q] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(gc + (size_t)y * (size_t)P.W) + xA * 4u);
+    }
+    const float half_guard = 0.5f - P.guard;
+    constexpr float rsum = (float)(1.0 / (1.0 + 4.0 * 0.8824969025845955 + 4.0 * 0.7788007830714049));
+    // a row as its horizontal sums, three (four) channels
+    struct Row { float h[4]; };
+    bool w4 = false;                                      // (uniform) a colour alpha has been met: the fourth channel's sums from here on
+    auto load_row = [&](uint32_t cc, Row& o) {
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cc, 0x138, 0xf, 0xf, false);     // wave_shr:1 -- lane l gets lane l - 1's
+        const uint32_t cr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cc, 0x130, 0xf, 0xf, false);     // wave_shl:1 -- lane l gets lane l + 1's
+        if (__ballot((cc >> 24) != 0u) != 0ull) w4 = true;
+        o.h[0] = __builtin_fmaf((float)(cl & 0xFFu), kGauss1, __builtin_fmaf((float)(cr & 0xFFu), kGauss1, (float)(cc & 0xFFu)));
+        o.h[1] = __builtin_fmaf((float)((cl >> 8) & 0xFFu), kGauss1, __builtin_fmaf((float)((cr >> 8) & 0xFFu), kGauss1, (float)((cc >> 8) & 0xFFu)));
+        o.h[2] = __builtin_fmaf((float)((cl >> 16) & 0xFFu), kGauss1, __builtin_fmaf((float)((cr >> 16) & 0xFFu), kGauss1, (float)((cc >> 16) & 0xFFu)));
+        o.h[3] = w4 ? __builtin_fmaf((float)(cl >> 24), kGauss1, __builtin_fmaf((float)(cr >> 24), kGauss1, (float)(cc >> 24))) : 0.0f;
+    };
+    Row rows[3];
+    load_row(code[0], rows[0]);
+    load_row(code[1], rows[1]);
+    uint32_t n = 0u;                                      // (uniform) pixels listed so far
+    const bool col_ok = l >= 1 && l <= OW && px < P.W;
+#pragma unroll
+    for (int q = 0; q < SEG; q++) {
+        load_row(code[q + 2], rows[(q + 2) % 3]);
+        const int py = ys + q;
+        if (py < ye) {                                    // uniform
+            const Row& up = rows[q % 3]; const Row& me = rows[(q + 1) % 3]; const Row& dn = rows[(q + 2) % 3];
+            float a[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) a[ch] = (ch == 3 && !w4) ? 0.0f : __builtin_fmaf(up.h[ch], kGauss1, __builtin_fmaf(dn.h[ch], kGauss1, me.h[ch]));
+            const float y0f = __builtin_fmaf(a[0], rsum, 0.5f), y1f = __builtin_fmaf(a[1], rsum, 0.5f), y2f = __builtin_fmaf(a[2], rsum, 0.5f);
+            const float f0 = __builtin_amdgcn_fractf(y0f), f1 = __builtin_amdgcn_fractf(y1f), f2 = __builtin_amdgcn_fractf(y2f);
+            const uint32_t o0 = (uint32_t)y0f, o1 = (uint32_t)y1f, o2 = (uint32_t)y2f;
+            bool sure = !FLAG || (__builtin_fabsf(f0 - 0.5f) < half_guard && __builtin_fabsf(f1 - 0.5f) < half_guard && __builtin_fabsf(f2 - 0.5f) < half_guard);
+            uint32_t o3 = 0u;
+            if (w4) {
+                const float y3f = __builtin_fmaf(a[3], rsum, 0.5f), f3 = __builtin_amdgcn_fractf(y3f);
+                o3 = (uint32_t)y3f;
+                if (FLAG) sure = sure && __builtin_fabsf(f3 - 0.5f) < half_guard;
+            }
+            const uint32_t idx = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
+            if (col_ok) {
+                if (sure) reinterpret_cast<uint32_t*>(P.color_out)[idx] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+            }
+            if (FLAG) {
+                const uint64_t m = __ballot(col_ok && !sure);
+                if (m != 0ull) {                              // (uniform; rare) the listed pixels: the wave's own count, a lane's rank among the listers
+                    if (col_ok && !sure) {
+                        const uint32_t slot = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (slot < 64u) fl_px[slot] = idx;
+                    }
+                    n += (uint32_t)__builtin_popcountll(m);
+                }
+            }
+        }
+    }
+    if (FLAG && n != 0u) {
+        __syncthreads();
+        if (P.fix_counts && threadIdx.x == 0) atomicAdd(&P.fix_counts[(blockIdx.y * gridDim.x + blockIdx.x) & (VRT_DENOISE_SEGS - 1u)], n);
+        denoise_redo<false, true>(P, 1, n, n > 64u, x0, OW, ys, ye, fl_px, fx_w, fx_c);
+    }
+}
+
 hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
 {
     int per = p.sh.strip_rows + 2 * p.extend;
@@ -2737,6 +2840,15 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     int R = (int)sw;
     bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
     const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
+    if ((float)R == sw && R == 1 && inf && p.verified && !shipped && !(p.mode & VRT_DENOISE_FAST) && !p.no_p0) {
+        // pass 0 of the canonical taps, a wave to itself (k_denoise_p0): strips of 62 output columns x VRT_P0_SEG rows
+        const int strips = (p.W + 61) / 62;
+        const int strip_ext = p.sh.nranks == 1 ? p.H : per;
+        const int segs = (strip_ext + VRT_P0_SEG - 1) / VRT_P0_SEG;
+        dim3 g2((unsigned)strips, (unsigned)(segs * p.sh.n_local_strips));
+        hipLaunchKernelGGL((k_denoise_p0<true>), g2, dim3(64), 0, s, p, segs);
+    }
+    else
     // (a rank's 16-row strips are too short for it -- R rows above every segment only compute weights --: two passes over rank 0's strips of
     // 2 / 4 / 8 ranks 29.8 / 18.5 / 14.2 us against k_denoise_ver's 27.0 / 19.5 / 13.9, tools/exp_r4_k3_shard.py; bands of 64 rows and more take it)
     if ((float)R == sw && R >= 2 && R <= 5 && p.verified && !inf && !shipped && !p.no_pair && (p.sh.nranks == 1 || per >= 64)) {

@@ -220,6 +220,7 @@ struct DenoiseParams {
     int32_t tile16;            // development switch (context option "denoise_th16"): the tolerance kernel on 64 x 16 tiles instead of 64 x 8
     int32_t no_packed;         // development switch (context option "denoise_packed" = 0): the exact weighted pass tap by tap
     int32_t no_pair;           // development switch (context option "denoise_pair" = 0): k_denoise_ver for every verified pass
+    int32_t no_p0;             // development switch (context option "denoise_p0" = 0): pass 0 through k_denoise_ver
     int32_t pair_wgs;          // development switch (context option "denoise_pair_wgs" > 0): workgroups of a k_denoise_pair launch
     // the verified pass (k_denoise_ver, vrt_denoise_bound.h): scale factors on the integer code distances and on the position
     // distance (log2(e) / phi, the colour's also / 255^2, the normal's / (127^2 stepWidth^2); computed in double), the guard in
