@@ -2840,8 +2840,9 @@ hipError_t launch_denoise_pass(const DenoiseParams& p, hipStream_t s)
     int R = (int)sw;
     bool tiled = (float)R == sw && R >= 1 && R <= 5 && (p.sh.nranks == 1 || per % 4 == 0);
     const bool shipped = (p.mode & 1) == VRT_DENOISE_AS_SHIPPED;
-    if ((float)R == sw && R == 1 && inf && p.verified && !shipped && !(p.mode & VRT_DENOISE_FAST) && !p.no_p0) {
-        // pass 0 of the canonical taps, a wave to itself (k_denoise_p0): strips of 62 output columns x VRT_P0_SEG rows
+    if ((float)R == sw && R == 1 && inf && p.verified && !shipped && !p.no_p0) {
+        // pass 0 of the canonical taps, a wave to itself (k_denoise_p0): strips of 62 output columns x VRT_P0_SEG rows.  (VRT_DENOISE_FAST too:
+        // its pass 0 has always been exact, and this is 8 us against the literal kernel's 11.7.)
         const int strips = (p.W + 61) / 62;
         const int strip_ext = p.sh.nranks == 1 ? p.H : per;
         const int segs = (strip_ext + VRT_P0_SEG - 1) / VRT_P0_SEG;
