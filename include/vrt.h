@@ -157,11 +157,12 @@ int  vrt_ctx_synchronize(vrt_ctx* ctx);                     /* device.waitIdle()
  *                                     "xcd_regions" (0 -- until round 3 VRT_XCD_REGIONS was on by default; as a three-dimensional grid the
  *                                     form ran 30.0 or 33.6 us per bench frame from one process to the next, so it is opt-in now)
  *   vrt_denoise:                      "denoise_packed" (1), "denoise_verified" (1), "denoise_pair" (1: verified passes of the canonical taps
- *                                     with offsets 2 .. 5 compute every weight once, k_denoise_pair; 0: k_denoise_ver), "denoise_p0" (1: pass 0 through k_denoise_p0), "denoise_th16" (0: the tolerance kernel's 64 x 16 tiles
+ *                                     with offsets 2 .. 5 compute every weight once, k_denoise_pair; 0: k_denoise_ver), "denoise_p0" (1: pass 0 through k_denoise_p0), "denoise_pair_wgs" (0; experiments: workgroups of a
+ *                                     k_denoise_pair launch), "denoise_th16" (0: the tolerance kernel's 64 x 16 tiles
  *                                     are an experiment), and the tests' handles on the verified pass "denoise_guard_div8" (0), "denoise_count" (0)
  *   scene creation:                   "open_cells" (1), "df_prefetch" (1), "df_own" (1)
  * The environment seeds them ONCE, at vrt_ctx_create (VRT_TILE_TAGS=0, VRT_SKY_FAST=0, ...); nothing on the render path calls
- * getenv.  Unknown name: VRT_ERR_INVALID. */
+ * getenv.  Values are non-negative integers (the switches: 0 / 1; a negative value is stored as 0).  Unknown name: VRT_ERR_INVALID. */
 int  vrt_ctx_set_option(vrt_ctx* ctx, const char* name, int32_t value);
 int  vrt_ctx_get_option(vrt_ctx* ctx, const char* name, int32_t* value);
 const char* vrt_last_error(void);
